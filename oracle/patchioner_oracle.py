@@ -1,0 +1,466 @@
+"""CPU oracle for the Patch-ioner hot path (TEST INFRASTRUCTURE -- never the product path).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module.  It is a plain PyTorch-CPU fp32 restatement of the reference's algorithm, kept
+deliberately *as the reference executes it* (no KV cache, logits for every position, the memory
+bank re-normalised and streamed three times per call, python loops over boxes / trace points), so
+that timing it stands in for "the reference CPU path" (BASELINE.md section 3).
+
+Pinning status
+--------------
+* a4-a15 (attention read-out, region weighting, projection, decoder, routing): PINNED against the
+  reference's own python modules executed in the build container through
+  ``tools/oracle/refshim.py``; the resulting vectors are committed under ``tests/golden/`` together
+  with the generator ``tools/oracle/gen_golden.py``.
+* a2 (the DINOv2 ViT): the arithmetic lives in the third-party ``facebookresearch/dinov2``
+  torch.hub package (unpinned, not vendored under /root/reference) -> "parity unpinned" against
+  the reference itself.  ``DinoV2Oracle`` restates the published architecture and is cross-checked
+  against the independent ``transformers.Dinov2WithRegistersModel`` port (fixture
+  ``tests/golden/vit_hf_crosscheck.npz``).
+
+Every function cites the reference file:line it follows (P/ = /root/reference/Patch-ioner/).
+"""
+from __future__ import annotations
+
+import math
+import random
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------------
+# a2  DINOv2 ViT (third-party; public architecture restated)
+# --------------------------------------------------------------------------------------------
+
+
+class DinoV2Oracle:
+    """``DinoVisionTransformer.forward(imgs, is_training=True)`` as called at P/src/model.py:783.
+
+    ``w`` is a state dict in the hub model's own naming (``cls_token``, ``pos_embed``,
+    ``register_tokens``, ``patch_embed.proj.*``, ``blocks.{i}.{norm1,attn.qkv,attn.proj,ls1,norm2,
+    mlp.fc1,mlp.fc2,ls2}.*``, ``norm.*``).  Registers models: interpolate_antialias=True,
+    interpolate_offset=0.0 (hub ``_reg`` entry points).
+    """
+
+    def __init__(self, w: Dict[str, torch.Tensor], num_heads: int, patch_size: int = 14,
+                 num_register_tokens: int = 4, eps: float = 1e-6):
+        self.w = {k: v.detach().float().cpu() for k, v in w.items()}
+        self.num_heads = num_heads
+        self.patch_size = patch_size
+        self.R = num_register_tokens
+        self.eps = eps
+        self.depth = 1 + max(int(k.split(".")[1]) for k in self.w if k.startswith("blocks."))
+        self.D = self.w["cls_token"].shape[-1]
+        self.last_qkv: Optional[torch.Tensor] = None  # what the reference's forward hook captures
+
+    def pos_embed_for(self, n_h: int, n_w: int) -> torch.Tensor:
+        pe = self.w["pos_embed"]
+        N = pe.shape[1] - 1
+        M = int(math.sqrt(N))
+        assert M * M == N
+        if n_h * n_w == N and n_h == n_w:
+            return pe
+        cls_pe, patch_pe = pe[:, :1], pe[:, 1:]
+        patch_pe = F.interpolate(patch_pe.reshape(1, M, M, self.D).permute(0, 3, 1, 2),
+                                 size=(n_h, n_w), mode="bicubic", antialias=True)
+        patch_pe = patch_pe.permute(0, 2, 3, 1).reshape(1, n_h * n_w, self.D)
+        return torch.cat([cls_pe, patch_pe], dim=1)
+
+    def tokens(self, imgs: torch.Tensor) -> torch.Tensor:
+        B, _, H, W = imgs.shape
+        p = self.patch_size
+        x = F.conv2d(imgs.float(), self.w["patch_embed.proj.weight"], self.w["patch_embed.proj.bias"],
+                     stride=p)
+        n_h, n_w = x.shape[-2:]
+        x = x.flatten(2).transpose(1, 2)
+        x = torch.cat([self.w["cls_token"].expand(B, -1, -1), x], dim=1)
+        x = x + self.pos_embed_for(n_h, n_w)
+        if self.R:
+            x = torch.cat([x[:, :1], self.w["register_tokens"].expand(B, -1, -1), x[:, 1:]], dim=1)
+        return x
+
+    def block(self, i: int, x: torch.Tensor, capture_qkv: bool = False) -> torch.Tensor:
+        w, D, h = self.w, self.D, self.num_heads
+        pre = "blocks.%d." % i
+        B, T, _ = x.shape
+        y = F.layer_norm(x, (D,), w[pre + "norm1.weight"], w[pre + "norm1.bias"], self.eps)
+        qkv = F.linear(y, w[pre + "attn.qkv.weight"], w[pre + "attn.qkv.bias"])
+        if capture_qkv:
+            self.last_qkv = qkv
+        q, k, v = qkv.reshape(B, T, 3, h, D // h).permute(2, 0, 3, 1, 4)
+        attn = (q * (D // h) ** -0.5) @ k.transpose(-2, -1)
+        attn = attn.softmax(dim=-1)
+        y = (attn @ v).transpose(1, 2).reshape(B, T, D)
+        y = F.linear(y, w[pre + "attn.proj.weight"], w[pre + "attn.proj.bias"])
+        x = x + y * w[pre + "ls1.gamma"]
+        y = F.layer_norm(x, (D,), w[pre + "norm2.weight"], w[pre + "norm2.bias"], self.eps)
+        y = F.linear(y, w[pre + "mlp.fc1.weight"], w[pre + "mlp.fc1.bias"])
+        y = F.gelu(y)  # exact erf GELU
+        y = F.linear(y, w[pre + "mlp.fc2.weight"], w[pre + "mlp.fc2.bias"])
+        return x + y * w[pre + "ls2.gamma"]
+
+    def __call__(self, imgs: torch.Tensor) -> Dict[str, torch.Tensor]:
+        x = self.tokens(imgs)
+        for i in range(self.depth):
+            x = self.block(i, x, capture_qkv=(i == self.depth - 1))
+        xn = F.layer_norm(x, (self.D,), self.w["norm.weight"], self.w["norm.bias"], self.eps)
+        R = self.R
+        return {"x_norm_clstoken": xn[:, 0], "x_norm_regtokens": xn[:, 1:R + 1],
+                "x_norm_patchtokens": xn[:, R + 1:], "x_prenorm": x}
+
+
+# --------------------------------------------------------------------------------------------
+# a4 / a5  CLS-row attention read-out and attention-weighted means
+# --------------------------------------------------------------------------------------------
+
+
+def process_self_attention(qkv_out: torch.Tensor, batch_size: int, num_tokens: int, num_attn_heads: int,
+                           embed_dim: int, scale: float, num_global_tokens: int):
+    """P/src/dino_extraction.py:24-34 (materialises the full [B,H,T,T] product, as the reference)."""
+    qkv = qkv_out.reshape(batch_size, num_tokens, 3, num_attn_heads,
+                          embed_dim // num_attn_heads).permute(2, 0, 3, 1, 4)
+    q, k = qkv[0] * scale, qkv[1]
+    attn = q @ k.transpose(-2, -1)
+    maps = attn[:, :, 0, num_global_tokens:]
+    self_attn = maps.mean(dim=1).softmax(dim=-1)
+    return self_attn, maps
+
+
+def attention_weighted_means(self_attn, maps, patch_tokens):
+    """P/src/model.py:869-872."""
+    avg_self_attn_token = (self_attn.unsqueeze(-1) * patch_tokens).mean(dim=1)
+    maps_sm = maps.softmax(dim=-1)
+    disentangled = (patch_tokens.unsqueeze(1) * maps_sm.unsqueeze(-1)).mean(dim=2)
+    return avg_self_attn_token, disentangled
+
+
+# --------------------------------------------------------------------------------------------
+# a6  traces
+# --------------------------------------------------------------------------------------------
+
+
+def map_traces_to_grid(traces: Sequence[dict], n_patch: int) -> torch.Tensor:
+    """P/src/bbox_utils.py:158-168 (double-precision ``int(x / (1.0/n))``, clamp, closed [0,1])."""
+    grid = torch.zeros((n_patch, n_patch))
+    patch_size = 1.0 / n_patch
+    for tr in traces:
+        x, y = tr["x"], tr["y"]
+        if 0 <= x <= 1 and 0 <= y <= 1:
+            gx, gy = int(x / patch_size), int(y / patch_size)
+            grid[min(gy, n_patch - 1), min(gx, n_patch - 1)] += 1
+    return grid
+
+
+def trace_embeds(patch_tokens: torch.Tensor, traces: Sequence[Sequence[dict]],
+                 self_attn: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """P/src/model.py:1049-1054: mean over n*n cells (NOT over the point count)."""
+    bs, n2, D = patch_tokens.shape
+    n = int(n2 ** 0.5)
+    rel = torch.stack([map_traces_to_grid(t, n) for t in traces], dim=0)
+    if self_attn is not None:
+        rel = self_attn.view(rel.shape) * rel
+    return (rel.unsqueeze(-1) * patch_tokens.view(bs, n, n, D)).mean(dim=(1, 2))
+
+
+# --------------------------------------------------------------------------------------------
+# a7 / a8  boxes and whole-image gaussian
+# --------------------------------------------------------------------------------------------
+
+
+def extract_bboxes_feats(patch_embeddings: torch.Tensor, bboxes: torch.Tensor, gaussian_avg=False,
+                         gaussian_bbox_variance=0.5, get_single_embedding_per_image=False,
+                         patch_size=14, attention_map: Optional[torch.Tensor] = None,
+                         rng: Optional[random.Random] = None):
+    """P/src/bbox_utils.py:8-109, including: in-place ``bboxes //= patch_size`` on the caller's
+    tensor, inclusive slices with python clamping / negative wrap, in-place renormalisation of the
+    attention slice (affects later overlapping boxes), NaN for empty regions."""
+    N, N_boxes = patch_embeddings.shape[0], bboxes.shape[1]
+    g = int(patch_embeddings.shape[1] ** 0.5)
+    rng = rng or random
+    bboxes //= patch_size
+    bb = bboxes.int()
+    pe = patch_embeddings.view(N, g, g, -1)
+    if attention_map is not None:
+        attention_map = attention_map.view(N, g, g)
+    total = torch.zeros(N, g, g)
+    x1, y1, w, h = bb.unbind(-1)
+    x2, y2 = x1 + w, y1 + h
+    means = []
+    for i in range(N):
+        image_means = []
+        for j in range(N_boxes):
+            if bb[i, j].sum().item() < 0 and get_single_embedding_per_image:
+                continue
+            ys, xs = slice(int(y1[i, j]), int(y2[i, j]) + 1), slice(int(x1[i, j]), int(x2[i, j]) + 1)
+            region = pe[i, ys, xs, :]
+            if attention_map is not None:
+                pw = attention_map[i, ys, xs]
+                pw /= pw.sum()
+                total[i, ys, xs] += pw
+                mean = (region * pw.unsqueeze(-1)).sum(dim=(0, 1))
+            elif gaussian_avg:
+                hs, ws = region.shape[:2]
+                yc, xc = torch.meshgrid(torch.linspace(-1, 1, hs), torch.linspace(-1, 1, ws), indexing="ij")
+                if gaussian_bbox_variance == 0:
+                    pw = torch.zeros((hs, ws))
+                    cy = [hs // 2] if hs % 2 == 1 else [hs // 2 - 1, hs // 2]
+                    cx = [ws // 2] if ws % 2 == 1 else [ws // 2 - 1, ws // 2]
+                    pw[rng.choice(cy), rng.choice(cx)] = 1.0
+                else:
+                    pw = torch.exp(-(xc ** 2 + yc ** 2) / gaussian_bbox_variance)
+                    pw = pw / pw.sum()
+                mean = (region * pw.unsqueeze(-1)).sum(dim=(0, 1))
+                total[i, ys, xs] += pw
+            else:
+                hs, ws = region.shape[:2]
+                total[i, ys, xs] += torch.ones(hs, ws) / (hs * ws)
+                mean = region.mean(dim=(0, 1))
+            image_means.append(mean)
+        if not get_single_embedding_per_image:
+            means.append(torch.stack(image_means))
+    total /= total.sum(dim=(1, 2), keepdim=True)
+    if not get_single_embedding_per_image:
+        return torch.stack(means)
+    return (total.unsqueeze(-1) * pe).sum(dim=(1, 2))
+
+
+def compute_region_means(patch_embeddings: torch.Tensor, variance: float,
+                         rng: Optional[random.Random] = None) -> torch.Tensor:
+    """P/src/model.py:45-94."""
+    N = patch_embeddings.shape[0]
+    g = int(patch_embeddings.shape[1] ** 0.5)
+    pe = patch_embeddings.view(N, g, g, -1)
+    rng = rng or random
+    lin = torch.linspace(-1, 1, g)
+    yy, xx = torch.meshgrid(lin, lin, indexing="ij")
+    if variance == 0:
+        pw = torch.zeros(N, g, g)
+        opts = [g // 2] if g % 2 == 1 else [g // 2 - 1, g // 2]
+        for i in range(N):
+            cy = rng.choice(opts)
+            cx = rng.choice(opts)
+            pw[i, cy, cx] = 1.0
+    elif variance >= 100:
+        pw = torch.full((N, g, g), 1 / (g * g))
+    else:
+        wts = torch.exp(-(xx ** 2 + yy ** 2) / variance)
+        pw = (wts / wts.sum()).unsqueeze(0).expand(N, -1, -1)
+    return (pe * pw.unsqueeze(-1)).sum(dim=(1, 2))
+
+
+# --------------------------------------------------------------------------------------------
+# a9 / a10  memory projection and pseudo-inverse inversion
+# --------------------------------------------------------------------------------------------
+
+
+def project(image_embedding: torch.Tensor, bank: torch.Tensor, temperature: float = 0.01,
+            normalize: bool = False, return_n_best_sims: Optional[int] = None):
+    """P/src/decap/im2txtprojection/im2txtprojection.py:353-385 (three passes over the bank; the
+    query is L2-normalised IN PLACE on the caller's tensor, line 368)."""
+    bank_n = bank / bank.norm(dim=-1, keepdim=True)
+    image_embedding /= image_embedding.norm(dim=-1, keepdim=True)
+    sim = image_embedding @ bank_n.T.float()
+    sm = (sim / temperature).softmax(dim=-1)
+    out = sm @ bank.float()
+    if normalize:
+        out /= out.norm(dim=-1, keepdim=True)
+    if return_n_best_sims:
+        return out, sim.sort(dim=-1, descending=True).values[:, :return_n_best_sims].tolist()
+    return out
+
+
+def get_pseudo_inverse(A: torch.Tensor) -> torch.Tensor:
+    """P/src/embedding_utils.py:3-15."""
+    U, S, Vh = torch.linalg.svd(A, full_matrices=False)
+    S_pinv = torch.zeros_like(S)
+    nz = S > 1e-10
+    S_pinv[nz] = 1.0 / S[nz]
+    return Vh.T @ torch.diag(S_pinv) @ U.T
+
+
+def revert_transformation(features, A_pinv, b):
+    """P/src/embedding_utils.py:17-25."""
+    return (features - b) @ A_pinv.t()
+
+
+# --------------------------------------------------------------------------------------------
+# a11 / a12  DeCap decoder (GPT-2 4L/4H/768, one-token prefix), greedy, NO KV cache
+# --------------------------------------------------------------------------------------------
+
+
+def gelu_new(x):
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
+
+
+class DeCapOracle:
+    """``DeCap`` (P/src/decap/decap.py:61-79) + the GPT2LMHeadModel math it instantiates
+    (transformers==4.46.3 ``modeling_gpt2``: Conv1D = x @ W[in,out] + b, pre-LN blocks, eps 1e-5,
+    gelu_new, causal softmax(QK^T / sqrt(d_head)), tied LM head).  ``w`` uses the checkpoint's own
+    key names (``clip_project.model.0.*``, ``decoder.transformer.*``)."""
+
+    def __init__(self, w: Dict[str, torch.Tensor], n_head: int = 4, eps: float = 1e-5):
+        self.w = {k: v.detach().float().cpu() for k, v in w.items()}
+        self.n_head = n_head
+        self.eps = eps
+        self.n_layer = 1 + max(int(k.split(".")[3]) for k in self.w if k.startswith("decoder.transformer.h."))
+        self.E = self.w["decoder.transformer.wte.weight"].shape[1]
+
+    def clip_project(self, x):
+        return F.linear(x, self.w["clip_project.model.0.weight"], self.w["clip_project.model.0.bias"])
+
+    def gpt2_logits(self, inputs_embeds: torch.Tensor) -> torch.Tensor:
+        """Full forward over [N,S,E] -> logits [N,S,V] (all positions, as the reference executes)."""
+        w, E, H = self.w, self.E, self.n_head
+        N, S, _ = inputs_embeds.shape
+        x = inputs_embeds + w["decoder.transformer.wpe.weight"][:S].unsqueeze(0)
+        mask = torch.tril(torch.ones(S, S, dtype=torch.bool))
+        for l in range(self.n_layer):
+            p = "decoder.transformer.h.%d." % l
+            y = F.layer_norm(x, (E,), w[p + "ln_1.weight"], w[p + "ln_1.bias"], self.eps)
+            qkv = y @ w[p + "attn.c_attn.weight"] + w[p + "attn.c_attn.bias"]
+            q, k, v = qkv.split(E, dim=2)
+            q = q.view(N, S, H, E // H).transpose(1, 2)
+            k = k.view(N, S, H, E // H).transpose(1, 2)
+            v = v.view(N, S, H, E // H).transpose(1, 2)
+            att = (q @ k.transpose(-1, -2)) / math.sqrt(E // H)
+            att = att.masked_fill(~mask, torch.finfo(att.dtype).min).softmax(dim=-1)
+            y = (att @ v).transpose(1, 2).reshape(N, S, E)
+            y = y @ w[p + "attn.c_proj.weight"] + w[p + "attn.c_proj.bias"]
+            x = x + y
+            y = F.layer_norm(x, (E,), w[p + "ln_2.weight"], w[p + "ln_2.bias"], self.eps)
+            y = gelu_new(y @ w[p + "mlp.c_fc.weight"] + w[p + "mlp.c_fc.bias"])
+            y = y @ w[p + "mlp.c_proj.weight"] + w[p + "mlp.c_proj.bias"]
+            x = x + y
+        x = F.layer_norm(x, (E,), w["decoder.transformer.ln_f.weight"], w["decoder.transformer.ln_f.bias"],
+                         self.eps)
+        return x @ w["decoder.transformer.wte.weight"].t()
+
+    def decode_ids(self, clip_features: torch.Tensor, entry_length: int = 30):
+        """P/src/decap/decap.py:116-155: 30 full forwards over the growing sequence; returns
+        (ids [N,30] int64, per-token log-probs [N,30], top-2 logit margin [N,30])."""
+        emb = self.clip_project(clip_features).view(clip_features.shape[0], 1, -1)
+        wte = self.w["decoder.transformer.wte.weight"]
+        ids, lps, margins = [], [], []
+        for _ in range(entry_length):
+            logits = self.gpt2_logits(emb)[:, -1, :]
+            probs = F.softmax(logits, -1)
+            nxt = torch.argmax(probs, -1).unsqueeze(1)
+            lps.append(torch.log(probs).gather(1, nxt))
+            top2 = logits.topk(2, dim=-1).values
+            margins.append((top2[:, 0] - top2[:, 1]).unsqueeze(1))
+            ids.append(nxt)
+            emb = torch.cat((emb, wte[nxt]), dim=1)
+        return torch.cat(ids, 1), torch.cat(lps, 1), torch.cat(margins, 1)
+
+
+def ids_to_captions(ids, decode_fn, return_start_end_tokens=False) -> Optional[List[str]]:
+    """P/src/decap/decap.py:162-181: one failure (KeyError for id >= 49408) voids the whole batch."""
+    try:
+        outs = []
+        for row in ids:
+            s = decode_fn([int(t) for t in row])
+            s = s.split("<|endoftext|>")[0]
+            if not return_start_end_tokens:
+                s = s.replace("<|startoftext|>", "")
+            else:
+                s += "<|endoftext|>"
+            outs.append(s)
+        return outs
+    except Exception:
+        return None
+
+
+# --------------------------------------------------------------------------------------------
+# a14 / a15  routing: caption_tokens and forward (DINO + DeCap/CapDec configs)
+# --------------------------------------------------------------------------------------------
+
+
+class PatchionerOracle:
+    """The reference ``Patchioner`` glue for the DINOv2 + DeCap/CapDec configs
+    (P/src/model.py:718-1058, 1392-1423), over the oracle pieces above."""
+
+    def __init__(self, vit: DinoV2Oracle, decoder: DeCapOracle, bank: Optional[torch.Tensor],
+                 decode_fn, normalize: bool = True, crop_dim: int = 224, num_attn_heads: int = 16,
+                 scale: float = 0.125, A_pinv=None, b=None):
+        self.vit, self.decoder, self.bank = vit, decoder, bank
+        self.decode_fn = decode_fn
+        self.normalize = normalize
+        self.patch_size = vit.patch_size
+        self.num_global_tokens = 1 + vit.R
+        self.num_tokens = self.num_global_tokens + crop_dim // self.patch_size * crop_dim // self.patch_size
+        self.embed_dim = vit.D
+        self.num_attn_heads, self.scale = num_attn_heads, scale
+        self.A_pinv, self.b = A_pinv, b
+        self.last_ids = None
+
+    def caption_tokens(self, tokens, project_flag=True, compute_scores=False):
+        if self.bank is None:
+            project_flag = False
+        x = project(tokens, self.bank, normalize=self.normalize) if project_flag else tokens
+        if self.A_pinv is not None:
+            x = revert_transformation(x, self.A_pinv, self.b)
+        ids, lps, _ = self.decoder.decode_ids(x)
+        self.last_ids = ids
+        caps = ids_to_captions(ids.tolist(), self.decode_fn)
+        if compute_scores:
+            return caps, torch.exp(lps.sum(-1)).tolist()
+        return caps
+
+    def forward(self, imgs, get_cls_capt=True, get_avg_self_attn_capt=False, bboxes=None, traces=None,
+                get_controllable_capts=False, bs_factor=4, gaussian_avg=False, gaussian_bbox_variance=0.5,
+                get_avg_patch_capt=False, gaussian_img_variance=1, use_attn_map_for_bboxes=False,
+                use_attention_tracing=False, compute_scores=False):
+        outs = {}
+        bs = imgs.shape[0]
+        d = self.vit(imgs)
+        patches = d["x_norm_patchtokens"]
+        self_attn, maps = process_self_attention(self.vit.last_qkv, bs, self.num_tokens, self.num_attn_heads,
+                                                 self.embed_dim, self.scale, self.num_global_tokens)
+        avg_tok, _ = attention_weighted_means(self_attn, maps, patches)
+        D = patches.shape[-1]
+
+        def put(key, ret):
+            if compute_scores:
+                outs[key], outs[key + "_scores"] = ret
+            else:
+                outs[key] = ret
+
+        if get_cls_capt:
+            put("cls_capt", self.caption_tokens(d["x_norm_clstoken"], compute_scores=compute_scores))
+        if get_avg_self_attn_capt:
+            put("avg_self_attn_capt", self.caption_tokens(avg_tok, compute_scores=compute_scores))
+        if get_avg_patch_capt:
+            put("avg_patch_capt", self.caption_tokens(compute_region_means(patches, gaussian_img_variance),
+                                                      compute_scores=compute_scores))
+        if bboxes is not None and not get_controllable_capts:
+            n_boxes = bboxes.shape[1]
+            amap = self_attn if use_attn_map_for_bboxes else None
+            feats = extract_bboxes_feats(patches, bboxes, gaussian_avg=gaussian_avg,
+                                         gaussian_bbox_variance=gaussian_bbox_variance,
+                                         patch_size=self.patch_size, attention_map=amap).view(-1, D)
+            bbox_bs = bs * bs_factor
+            n_batch = math.ceil(feats.shape[0] / bbox_bs)
+            caps, scores = [], []
+            for i in range(n_batch):
+                s = i * bbox_bs
+                e = s + bbox_bs if i < n_batch - 1 else feats.shape[0]
+                ret = self.caption_tokens(feats[s:e], compute_scores=compute_scores)
+                if compute_scores:
+                    caps.extend(ret[0]); scores.extend(ret[1])
+                else:
+                    caps.extend(ret)
+            outs["bbox_capts"] = [caps[i * n_boxes:(i + 1) * n_boxes] for i in range(bs)]
+            if compute_scores:
+                outs["bbox_scores"] = [scores[i * n_boxes:(i + 1) * n_boxes] for i in range(bs)]
+        elif bboxes is not None and get_controllable_capts:
+            amap = self_attn if use_attn_map_for_bboxes else None
+            feats = extract_bboxes_feats(patches, bboxes, gaussian_avg=gaussian_avg,
+                                         gaussian_bbox_variance=gaussian_bbox_variance,
+                                         get_single_embedding_per_image=True, patch_size=self.patch_size,
+                                         attention_map=amap)
+            outs["set_controllable_capts"] = self.caption_tokens(feats)
+        if traces is not None:
+            emb = trace_embeds(patches, traces, self_attn if use_attention_tracing else None)
+            outs["trace_capts"] = self.caption_tokens(emb)
+        return outs

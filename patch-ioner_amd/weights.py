@@ -1,0 +1,131 @@
+"""Seeded synthetic weights in the reference checkpoints' own key names.
+
+There is no network on the build or GPU boxes, so the DINOv2 hub weights
+(P/src/model.py:342-343), the DeCap decoder checkpoint (P/src/decap/decap.py:188-222) and the
+text memory bank (P/src/decap/im2txtprojection/im2txtprojection.py:387-407) are replaced by
+deterministic synthetic tensors of the same shapes and names.  Real checkpoints
+load through the same dict interface (see ``model.Patchioner.from_config``).
+
+All generators use a CPU ``torch.Generator`` so the numbers are identical on every box.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+DINO_ARCHS = {
+    # name fragment -> (embed_dim, depth, heads)
+    "vits14": (384, 12, 6),
+    "vitb14": (768, 12, 12),
+    "vitl14": (1024, 24, 16),
+}
+
+
+def dino_arch(dino_model: str):
+    for k, v in DINO_ARCHS.items():
+        if k in dino_model:
+            return v
+    raise ValueError("unsupported DINOv2 model name %r" % (dino_model,))
+
+
+def _tn(g, shape, std):
+    t = torch.empty(shape)
+    torch.nn.init.trunc_normal_(t, std=std, a=-2 * std, b=2 * std, generator=g)
+    return t
+
+
+def synth_dinov2(seed: int, dino_model: str = "dinov2_vitb14_reg", depth: int | None = None,
+                 pretrain_grid: int = 37) -> Dict[str, torch.Tensor]:
+    """State dict shaped like ``torch.hub.load('facebookresearch/dinov2', dino_model).state_dict()``."""
+    D, full_depth, _ = dino_arch(dino_model)
+    depth = depth or full_depth
+    R = 4 if "reg" in dino_model else 0
+    g = torch.Generator().manual_seed(seed)
+    w: Dict[str, torch.Tensor] = {}
+    w["cls_token"] = _tn(g, (1, 1, D), 0.02)
+    w["pos_embed"] = _tn(g, (1, 1 + pretrain_grid * pretrain_grid, D), 0.02)
+    if R:
+        w["register_tokens"] = _tn(g, (1, R, D), 0.02)
+    w["mask_token"] = torch.zeros(1, D)
+    w["patch_embed.proj.weight"] = _tn(g, (D, 3, 14, 14), 0.02)
+    w["patch_embed.proj.bias"] = _tn(g, (D,), 0.02)
+    for i in range(depth):
+        p = "blocks.%d." % i
+        for ln in ("norm1", "norm2"):
+            w[p + ln + ".weight"] = 0.5 + torch.rand(D, generator=g)
+            w[p + ln + ".bias"] = _tn(g, (D,), 0.02)
+        # q/k rows scaled up so the attention maps are peaky (as trained DINOv2 maps are)
+        qkv = _tn(g, (3 * D, D), 0.02)
+        qkv[: 2 * D] *= 2.5
+        w[p + "attn.qkv.weight"] = qkv
+        w[p + "attn.qkv.bias"] = _tn(g, (3 * D,), 0.02)
+        w[p + "attn.proj.weight"] = _tn(g, (D, D), 0.02)
+        w[p + "attn.proj.bias"] = _tn(g, (D,), 0.02)
+        w[p + "ls1.gamma"] = 0.1 * (0.5 + torch.rand(D, generator=g))
+        w[p + "mlp.fc1.weight"] = _tn(g, (4 * D, D), 0.02)
+        w[p + "mlp.fc1.bias"] = _tn(g, (4 * D,), 0.02)
+        w[p + "mlp.fc2.weight"] = _tn(g, (D, 4 * D), 0.02)
+        w[p + "mlp.fc2.bias"] = _tn(g, (D,), 0.02)
+        w[p + "ls2.gamma"] = 0.1 * (0.5 + torch.rand(D, generator=g))
+    w["norm.weight"] = 0.5 + torch.rand(D, generator=g)
+    w["norm.bias"] = _tn(g, (D,), 0.02)
+    return w
+
+
+def synth_decap(seed: int, prefix_size: int = 768, n_layer: int = 4, n_embd: int = 768,
+                vocab: int = 50257, n_positions: int = 1024, tok_vocab: int = 49408,
+                std: float = 0.02) -> Dict[str, torch.Tensor]:
+    """State dict shaped like a DeCap checkpoint (``clip_project`` + ``decoder`` = GPT2LMHeadModel).
+
+    Embedding rows >= ``tok_vocab`` are zero: the LM head is tied, so their logits are exactly 0 and
+    a random-weight argmax never emits an id the CLIP tokenizer cannot decode.
+    """
+    g = torch.Generator().manual_seed(seed)
+    E = n_embd
+
+    def n(*shape):
+        return torch.randn(*shape, generator=g) * std
+
+    w: Dict[str, torch.Tensor] = {}
+    w["clip_project.model.0.weight"] = n(E, prefix_size)
+    w["clip_project.model.0.bias"] = n(E)
+    wte = n(vocab, E)
+    wte[tok_vocab:] = 0
+    w["decoder.transformer.wte.weight"] = wte
+    w["decoder.transformer.wpe.weight"] = n(n_positions, E)
+    for l in range(n_layer):
+        p = "decoder.transformer.h.%d." % l
+        w[p + "ln_1.weight"] = 0.5 + torch.rand(E, generator=g)
+        w[p + "ln_1.bias"] = n(E)
+        w[p + "attn.c_attn.weight"] = n(E, 3 * E)      # Conv1D: [in, out]
+        w[p + "attn.c_attn.bias"] = n(3 * E)
+        w[p + "attn.c_proj.weight"] = n(E, E)
+        w[p + "attn.c_proj.bias"] = n(E)
+        w[p + "ln_2.weight"] = 0.5 + torch.rand(E, generator=g)
+        w[p + "ln_2.bias"] = n(E)
+        w[p + "mlp.c_fc.weight"] = n(E, 4 * E)
+        w[p + "mlp.c_fc.bias"] = n(4 * E)
+        w[p + "mlp.c_proj.weight"] = n(4 * E, E)
+        w[p + "mlp.c_proj.bias"] = n(E)
+    w["decoder.transformer.ln_f.weight"] = 0.5 + torch.rand(E, generator=g)
+    w["decoder.transformer.ln_f.bias"] = n(E)
+    w["decoder.lm_head.weight"] = wte  # tied
+    return w
+
+
+def synth_bank(seed: int, rows: int, dim: int = 768) -> torch.Tensor:
+    """Text-embedding memory bank ``[rows, dim] ~ N(0,1)`` (un-normalised, as the DINOv2 configs keep it,
+    P/src/model.py:174)."""
+    g = torch.Generator().manual_seed(seed)
+    out = torch.empty(rows, dim)
+    step = 65536
+    for s in range(0, rows, step):
+        e = min(rows, s + step)
+        out[s:e] = torch.randn(e - s, dim, generator=g)
+    return out
+
+
+def synth_images(seed: int, batch: int, size: int = 224) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(batch, 3, size, size, generator=g)

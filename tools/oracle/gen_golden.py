@@ -1,0 +1,340 @@
+"""Generate ``tests/golden/*.npz`` by running the REFERENCE python modules (through ``refshim``) on the
+seeded inputs of ``tests/golden_cases.py``.  Run in the build container only:
+
+    python tools/oracle/gen_golden.py
+
+The committed fixtures hold inputs' seeds/parameters and the reference's OUTPUTS (data), never any
+reference source.  The ViT (third-party DINOv2, absent) is not pinned by these; ``vit_hf_crosscheck``
+is produced from the independent ``transformers`` port instead (second opinion, see oracle header).
+"""
+import copy
+import json
+import os
+import random
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import golden_cases as gc  # noqa: E402
+import refshim  # noqa: E402
+from dino_standin import DinoStandIn  # noqa: E402
+from patchioner_amd import weights as W  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_grad_enabled(False)
+torch.manual_seed(0)
+
+
+def save(name, **arrs):
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print("wrote %-28s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def gen_attn(ref):
+    c = gc.ATTN
+    qkv, patches = gc.attn_inputs()
+    T = c["G"] + c["n"] ** 2
+    self_attn, maps = ref.dino_extraction.process_self_attention(
+        qkv, c["B"], T, c["heads"], c["D"], c["scale"], c["G"], ret_self_attn_maps=True)
+    # the three inline lines of the reference forward (P/src/model.py:869-872)
+    avg = (self_attn.unsqueeze(-1) * patches).mean(dim=1)
+    maps_sm = maps.softmax(dim=-1)
+    dis = (patches.unsqueeze(1) * maps_sm.unsqueeze(-1)).mean(dim=2)
+    save("attn_readout", self_attn=self_attn, maps=maps, avg_self_attn_token=avg, disentangled=dis)
+
+
+def gen_traces(ref):
+    arrs = {}
+    for i, (n, pts) in enumerate(gc.trace_cases()):
+        arrs["grid%d" % i] = ref.bbox_utils.map_traces_to_grid(pts, n)
+    save("trace_grids", **arrs)
+
+
+def gen_boxes(ref):
+    f = ref.bbox_utils.extract_bboxes_feats
+    patches, attn = gc.box_patches(), gc.box_attn()
+    arrs = {}
+
+    def run(tag, boxes, **kw):
+        b = boxes.clone()
+        a = kw.pop("attention_map", None)
+        a = a.clone() if a is not None else None
+        out = f(patches.clone(), b, patch_size=gc.BOX["patch_size"], attention_map=a, **kw)
+        arrs[tag] = out
+        arrs[tag + "__boxes_after"] = b         # quirk: caller's tensor is floor-divided in place
+        if a is not None:
+            arrs[tag + "__attn_after"] = a      # quirk: attention slices renormalised in place
+
+    run("uniform", gc.boxes_regular())
+    run("gauss05", gc.boxes_regular(), gaussian_avg=True, gaussian_bbox_variance=0.5)
+    run("gauss10", gc.boxes_regular(), gaussian_avg=True, gaussian_bbox_variance=1.0)
+    run("attnmap", gc.boxes_regular(), attention_map=attn)
+    run("dummy_nan", gc.boxes_with_dummies(), gaussian_avg=True)
+    run("single_uniform", gc.boxes_with_dummies(), get_single_embedding_per_image=True)
+    run("single_gauss", gc.boxes_with_dummies(), gaussian_avg=True, gaussian_bbox_variance=0.5,
+        get_single_embedding_per_image=True)
+    run("single_attn", gc.boxes_with_dummies(), attention_map=attn, get_single_embedding_per_image=True)
+    run("center_odd", gc.boxes_odd_spans(), gaussian_avg=True, gaussian_bbox_variance=0)
+    random.seed(123)
+    run("center_even_seed123", gc.boxes_regular(), gaussian_avg=True, gaussian_bbox_variance=0)
+    save("bbox_feats", **arrs)
+
+
+def gen_region_means(ref):
+    patches = gc.box_patches()
+    arrs = {}
+    for v in gc.REGION_VARIANCES:
+        arrs["var_%s" % v] = ref.model.compute_region_means(patches.clone(), v)
+    random.seed(321)
+    arrs["var_0_seed321"] = ref.model.compute_region_means(patches.clone(), 0)
+    save("region_means", **arrs)
+
+
+def make_projector(ref, bank):
+    P = ref.im2txt.Im2TxtProjector
+    p = object.__new__(P)
+    p.device = torch.device("cpu")
+    p.embs_dataset = bank
+    p.text_dataset = None
+    return p
+
+
+def gen_project(ref):
+    arrs = {}
+    for tag, clustered in (("gauss", False), ("clustered", True)):
+        bank, q = gc.proj_inputs(clustered)
+        p = make_projector(ref, bank)
+        q1 = q.clone()
+        arrs[tag + "_norm"] = p.project(q1, normalize=True)
+        arrs[tag + "_q_after"] = q1                      # quirk: query normalised in place
+        arrs[tag + "_raw"] = p.project(q.clone(), normalize=False)
+        out, sims = p.project(q.clone(), normalize=True, return_n_best_sims=5)
+        arrs[tag + "_best5"] = np.asarray(sims, dtype=np.float32)
+    save("projection", **arrs)
+
+
+def build_ref_decap(ref, w, prefix_size=768):
+    m = ref.decap.DeCap(prefix_size)
+    missing, unexpected = m.load_state_dict(w, strict=False)
+    missing = [k for k in missing if not k.endswith(".attn.bias") and not k.endswith("masked_bias")]
+    assert not missing and not unexpected, (missing, unexpected)
+    return m.eval()
+
+
+def ref_decode(ref, model, feats, compute_scores=True):
+    got = []
+
+    def capture(ids):
+        got.append([int(t) for t in ids])
+        return ref.decap._Tokenizer.decode(ids)
+
+    ret = ref.decap.decoding_batched(model, feats, compute_scores=compute_scores, decoding_method=capture)
+    caps, scores = ret if compute_scores else (ret, None)
+    ids = torch.tensor(got, dtype=torch.int64)
+    # per-token log-probs / top-2 margins from ONE causal pass of the reference's own module
+    emb = torch.cat([model.clip_project(feats).view(feats.shape[0], 1, -1),
+                     model.decoder.transformer.wte(ids[:, :-1])], dim=1)
+    logits = model.decoder(inputs_embeds=emb).logits
+    lp = torch.log_softmax(logits, -1).gather(2, ids.unsqueeze(-1)).squeeze(-1)
+    assert torch.equal(logits.argmax(-1), ids), "causal re-run disagrees with the step-wise decode"
+    top2 = logits.topk(2, dim=-1).values
+    return caps, scores, ids, lp, top2[..., 0] - top2[..., 1]
+
+
+def gen_decoder(ref):
+    w = W.synth_decap(gc.DEC["seed_w"])
+    model = build_ref_decap(ref, w)
+    arrs, meta = {}, {}
+    for kind in ("unit", "raw"):
+        x = gc.decoder_prefixes(kind)
+        caps, scores, ids, lp, margin = ref_decode(ref, model, x)
+        arrs[kind + "_ids"] = ids
+        arrs[kind + "_logprob"] = lp
+        arrs[kind + "_margin"] = margin
+        arrs[kind + "_scores"] = np.asarray(scores, dtype=np.float64)
+        meta[kind + "_captions"] = caps
+        print("  decoder[%s]: min top-2 margin %.3e  median %.3f" % (kind, margin.min(), margin.median()))
+    arrs["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    save("decoder", **arrs)
+    return model
+
+
+def gen_tokenizer(ref):
+    tok = ref.decap._Tokenizer
+    rng = np.random.RandomState(9)
+    rows = [rng.randint(0, 49408, size=30).tolist() for _ in range(24)]
+    rows.append([49406, 320, 1125, 539, 49407, 320, 320])
+    rows.append([49407] + [0] * 5)
+    strs = [tok.decode(r) for r in rows]
+    # the byte table the product's detokeniser is built from (data derived from the BPE vocabulary asset)
+    table = [bytes([tok.byte_decoder[c] for c in tok.decoder[i]]) for i in range(len(tok.decoder))]
+    offs = np.zeros(len(table) + 1, dtype=np.uint32)
+    offs[1:] = np.cumsum([len(t) for t in table])
+    blob = np.frombuffer(b"".join(table), dtype=np.uint8)
+    asset = os.path.join(ROOT, "patch-ioner_amd", "assets")
+    os.makedirs(asset, exist_ok=True)
+    np.savez_compressed(os.path.join(asset, "clip_bpe_decode_table.npz"), offsets=offs, blob=blob)
+    save("tokenizer", ids=np.asarray([r + [-1] * (30 - len(r)) for r in rows], dtype=np.int64),
+         strings_json=np.frombuffer(json.dumps(strs).encode(), dtype=np.uint8))
+
+
+def gen_pinv(ref):
+    A = gc.randn(71, 768, 512) * 0.05          # synthetic stand-in for the Talk2DINO first Linear
+    b = gc.randn(72, 768) * 0.02
+    x = gc.randn(73, 6, 768)
+    A_pinv = ref.embedding_utils.get_pseudo_inverse(A)
+    y = ref.embedding_utils.revert_transformation(x, A_pinv=A_pinv, b=b)
+    save("pinv", A_pinv_rows=A_pinv[::32], y=y)
+
+
+def gen_e2e(ref):
+    c = gc.E2E
+    D, _, heads = W.dino_arch("dinov2_vitb14_reg")
+    vit_w = W.synth_dinov2(c["seed_vit"], depth=c["depth"])
+    standin = DinoStandIn(D, c["depth"], heads)
+    standin.load_state_dict(vit_w, strict=True)
+    dec_w = W.synth_decap(c["seed_dec"])
+    tmp = tempfile.NamedTemporaryFile(suffix=".pt", delete=False)
+    torch.save(dec_w, tmp.name)
+    orig_hub = torch.hub.load
+    torch.hub.load = lambda *a, **k: standin
+    try:
+        model = ref.model.Patchioner.from_config(
+            {"decap_weights": tmp.name, "prefix_size": 768, "support_memory_size": 0, "linear_talk2dino": False,
+             "dino_model": "dinov2_vitb14_reg", "normalize": True, "resize_dim": c["crop"], "crop_dim": c["crop"]},
+            device="cpu")
+    finally:
+        torch.hub.load = orig_hub
+        os.unlink(tmp.name)
+    model.eval()
+    imgs = W.synth_images(c["seed_img"], c["B"], c["crop"])
+    bank = W.synth_bank(c["seed_bank"], c["M"])
+    calls = []
+
+    def capture(ids):
+        calls[-1].append([int(t) for t in ids])
+        return ref.decap._Tokenizer.decode(ids)
+
+    model.decoding_method = capture
+    arrs, meta = {}, {}
+
+    def run(tag, with_bank, **kw):
+        model.im_proj = make_projector(ref, bank) if with_bank else None
+        calls.clear()
+        orig = ref.model.decoding_batched
+
+        def wrapped(*a, **k):
+            calls.append([])
+            return orig(*a, **k)
+
+        ref.model.decoding_batched = wrapped
+        try:
+            outs = model(imgs.clone(), **copy.deepcopy(kw))
+        finally:
+            ref.model.decoding_batched = orig
+        meta[tag] = outs
+        for i, ids in enumerate(calls):
+            arrs["%s__ids%d" % (tag, i)] = np.asarray(ids, dtype=np.int64)
+        # backbone tensors the reference saw (pins the stand-in == oracle ViT equivalence too)
+        return outs
+
+    traces, boxes = gc.e2e_traces(), gc.e2e_boxes()
+    for with_bank, cfg in ((True, "decap"), (False, "capdec")):
+        run(cfg + "_cls_trace", with_bank, get_cls_capt=True, traces=traces)
+        run(cfg + "_attn_family", with_bank, get_cls_capt=False, get_avg_self_attn_capt=True,
+            get_avg_patch_capt=True, gaussian_img_variance=1, traces=traces, use_attention_tracing=True)
+        run(cfg + "_bbox_gauss_scores", with_bank, get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True,
+            gaussian_bbox_variance=1.0, compute_scores=True, bs_factor=1)
+        run(cfg + "_bbox_attnmap", with_bank, get_cls_capt=False, bboxes=boxes.clone(), use_attn_map_for_bboxes=True)
+        run(cfg + "_controllable", with_bank, get_cls_capt=False, bboxes=boxes.clone(), get_controllable_capts=True,
+            gaussian_avg=True)
+    d = standin(imgs, is_training=True)
+    arrs["vit_cls"] = d["x_norm_clstoken"]
+    arrs["vit_patch_sample"] = d["x_norm_patchtokens"][:, ::37]
+    arrs["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    save("e2e", **arrs)
+
+
+def gen_vit_hf():
+    """Second opinion on the ViT restatement: the independent HF port, random weights mapped from ours."""
+    from transformers import Dinov2WithRegistersConfig, Dinov2WithRegistersModel
+    depth = 2
+    w = W.synth_dinov2(81, depth=depth)
+    cfg = Dinov2WithRegistersConfig(hidden_size=768, num_hidden_layers=depth, num_attention_heads=12, mlp_ratio=4,
+                                    image_size=518, patch_size=14, num_register_tokens=4, layerscale_value=1.0,
+                                    hidden_act="gelu", qkv_bias=True, use_swiglu_ffn=False, layer_norm_eps=1e-6,
+                                    attn_implementation="eager")
+    m = Dinov2WithRegistersModel(cfg).eval()
+    sd = {}
+    sd["embeddings.cls_token"] = w["cls_token"]
+    sd["embeddings.mask_token"] = w["mask_token"]
+    sd["embeddings.register_tokens"] = w["register_tokens"]
+    sd["embeddings.position_embeddings"] = w["pos_embed"]
+    sd["embeddings.patch_embeddings.projection.weight"] = w["patch_embed.proj.weight"]
+    sd["embeddings.patch_embeddings.projection.bias"] = w["patch_embed.proj.bias"]
+    for i in range(depth):
+        s, t = "blocks.%d." % i, "encoder.layer.%d." % i
+        q, k, v = w[s + "attn.qkv.weight"].chunk(3, 0)
+        qb, kb, vb = w[s + "attn.qkv.bias"].chunk(3, 0)
+        for nm, ww, bb in (("query", q, qb), ("key", k, kb), ("value", v, vb)):
+            sd[t + "attention.attention.%s.weight" % nm] = ww
+            sd[t + "attention.attention.%s.bias" % nm] = bb
+        sd[t + "attention.output.dense.weight"] = w[s + "attn.proj.weight"]
+        sd[t + "attention.output.dense.bias"] = w[s + "attn.proj.bias"]
+        sd[t + "norm1.weight"], sd[t + "norm1.bias"] = w[s + "norm1.weight"], w[s + "norm1.bias"]
+        sd[t + "norm2.weight"], sd[t + "norm2.bias"] = w[s + "norm2.weight"], w[s + "norm2.bias"]
+        sd[t + "layer_scale1.lambda1"] = w[s + "ls1.gamma"]
+        sd[t + "layer_scale2.lambda1"] = w[s + "ls2.gamma"]
+        sd[t + "mlp.fc1.weight"], sd[t + "mlp.fc1.bias"] = w[s + "mlp.fc1.weight"], w[s + "mlp.fc1.bias"]
+        sd[t + "mlp.fc2.weight"], sd[t + "mlp.fc2.bias"] = w[s + "mlp.fc2.weight"], w[s + "mlp.fc2.bias"]
+    sd["layernorm.weight"], sd["layernorm.bias"] = w["norm.weight"], w["norm.bias"]
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    arrs = {}
+    for size in (224, 518):
+        imgs = W.synth_images(82, 2, size)
+        try:
+            out = m(pixel_values=imgs, interpolate_pos_encoding=True).last_hidden_state
+        except TypeError:
+            out = m(pixel_values=imgs).last_hidden_state
+        arrs["out%d_cls" % size] = out[:, 0]
+        arrs["out%d_reg" % size] = out[:, 1:5]
+        arrs["out%d_patch_sample" % size] = out[:, 5::53]
+    save("vit_hf_crosscheck", **arrs)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = refshim.load()
+    only = set(sys.argv[1:])
+
+    def want(n):
+        return not only or n in only
+
+    if want("attn"): gen_attn(ref)
+    if want("traces"): gen_traces(ref)
+    if want("boxes"): gen_boxes(ref)
+    if want("region"): gen_region_means(ref)
+    if want("project"): gen_project(ref)
+    if want("decoder"): gen_decoder(ref)
+    if want("tokenizer"): gen_tokenizer(ref)
+    if want("pinv"): gen_pinv(ref)
+    if want("e2e"): gen_e2e(ref)
+    if want("vit_hf"): gen_vit_hf()
+
+
+if __name__ == "__main__":
+    main()
