@@ -1,0 +1,180 @@
+/*
+ * patchioner_hip.h -- C ABI of libpatchioner_hip.so, the MI355X (gfx950) implementation of the
+ * Patch-ioner captioning hot path.
+ *
+ * The reference (Ruggero1912/Patch-ioner) is pure Python on PyTorch: it has no FFI.  Each entry point
+ * below therefore replaces a *Python* function (or an inline block of Patchioner.forward) and cites
+ * it as P/<file>:<lines> with P = /root/reference/Patch-ioner.  The reference-side binding a
+ * maintainer would add is the ctypes stub shown in INTEGRATION.md (and shipped as
+ * patch-ioner_amd/_lib.py).
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no torch / HIP types (streams travel as void*).
+ *   - every function returns 0 on success or a negative pio_status; pio_last_error() gives the
+ *     message of the last failure on the calling thread.
+ *   - "dev" pointers are HIP device pointers owned by the caller; the library never frees them.
+ *     Weights, the memory bank copy and all workspaces are owned by the handle (allocated in
+ *     pio_create / pio_finalize_weights / pio_set_memory_bank; no allocation on the forward path).
+ *   - one handle per (process, GPU); calls on one handle are serialised by the caller; all work of a
+ *     call is enqueued on the given stream and nothing synchronises the device unless stated.
+ *   - all floating-point tensors crossing the ABI are fp32, row-major, contiguous.
+ */
+#ifndef PATCHIONER_HIP_H
+#define PATCHIONER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pio_context* pio_handle;
+typedef void* pio_stream; /* hipStream_t */
+
+typedef enum {
+  PIO_OK = 0,
+  PIO_ERR_INVALID_ARG = -1,
+  PIO_ERR_HIP = -2,           /* a HIP runtime call failed (message has the HIP error string) */
+  PIO_ERR_NOT_READY = -3,     /* weights / bank not loaded yet */
+  PIO_ERR_UNKNOWN_WEIGHT = -4,
+  PIO_ERR_SHAPE = -5,
+  PIO_ERR_CAPACITY = -6       /* batch / prefix count above what pio_create sized */
+} pio_status;
+
+/* Static model description; mirrors what Patchioner.__init__ derives from the YAML config
+ * (P/src/model.py:196-198, 285-286, 323-337) and decoder_config.pkl (P/src/decap/decap.py:66-71). */
+typedef struct {
+  /* ViT backbone (DINOv2 with registers) */
+  int32_t embed_dim;          /* 384 / 768 / 1024 */
+  int32_t depth;              /* 12 / 24 */
+  int32_t num_heads;          /* backbone heads (12 for ViT-B) */
+  int32_t patch_size;         /* 14 */
+  int32_t num_registers;      /* 4 for *_reg models, else 0 */
+  int32_t pretrain_grid;      /* 37: side of the learned position grid */
+  int32_t crop_dim;           /* input side in pixels; must be a multiple of patch_size */
+  float   vit_ln_eps;         /* 1e-6 */
+  /* CLS-attention read-out quirk: 16 heads and scale 0.125 whatever the backbone (model.py:336-337) */
+  int32_t readout_heads;
+  float   readout_scale;
+  /* DeCap decoder (GPT-2) */
+  int32_t dec_layers;         /* 4 */
+  int32_t dec_heads;          /* 4 */
+  int32_t dec_embd;           /* 768 */
+  int32_t dec_vocab;          /* 50257 */
+  int32_t dec_positions;      /* 1024 */
+  int32_t prefix_size;        /* clip_project input width (768, or 512 with the Talk2DINO inversion) */
+  float   dec_ln_eps;         /* 1e-5 */
+  /* capacities */
+  int32_t max_batch;          /* images per pio_vit_forward call */
+  int32_t max_prefixes;       /* prefixes per pio_decode_greedy / pio_mem_project call */
+  int32_t max_steps;          /* decode steps (reference: 30) */
+  /* numerics of the ViT MFMA path: 0 = fp16 operands, 1 = bf16 operands (fp32 accumulate either way) */
+  int32_t vit_operand_type;
+  int32_t device;             /* HIP device ordinal */
+} pio_config;
+
+const char* pio_last_error(void);
+const char* pio_version(void);
+
+/* -- a1: construction (replaces Patchioner.__init__ / from_config, P/src/model.py:98-662, 666-715) -- */
+int pio_create(const pio_config* cfg, pio_handle* out);
+int pio_destroy(pio_handle h);
+
+/* Upload one fp32 host tensor under its checkpoint key.  Keys are the reference checkpoints' own:
+ *   backbone: "cls_token", "pos_embed", "register_tokens", "patch_embed.proj.weight", ...,
+ *             "blocks.<i>.attn.qkv.weight", ..., "norm.bias"   (torch.hub dinov2 state_dict)
+ *   decoder : "clip_project.model.0.weight|bias", "decoder.transformer.wte.weight", ...
+ *             (DeCap checkpoint, P/src/decap/decap.py:61-79, 188-222)
+ *   inversion: "talk2dino.A_pinv" [prefix_size, embed_dim], "talk2dino.b" [embed_dim]
+ *             (P/src/model.py:618-627)
+ * Unknown keys return PIO_ERR_UNKNOWN_WEIGHT (callers doing strict=False loading ignore it). */
+int pio_load_weight(pio_handle h, const char* key, const float* host_data, const int64_t* shape, int32_t ndim);
+
+/* Pack everything for the device: operand-precision copies, [out,in] transposes of the GPT-2 Conv1D
+ * weights, bicubic-antialias interpolation of the position grid to crop_dim (DINOv2
+ * interpolate_pos_encoding; cached per resolution).  Must be called once after the last pio_load_weight. */
+int pio_finalize_weights(pio_handle h);
+
+/* -- a9 state: the text memory bank (Im2TxtProjector.embs_dataset,
+ *    P/src/decap/im2txtprojection/im2txtprojection.py:341-349).  Rows with zero norm are dropped as
+ *    the reference does; inverse norms are precomputed once.  `rows_kept` may be NULL. */
+int pio_set_memory_bank(pio_handle h, const float* host_bank, int64_t rows, int32_t dim, int64_t* rows_kept);
+
+/* Same, from a device-resident fp32 bank (copied; no zero-row filtering -- the caller guarantees none). */
+int pio_set_memory_bank_device(pio_handle h, const float* dev_bank, int64_t rows, int32_t dim);
+
+/* -- a2 + a3: backbone forward with the last block's fused-QKV output captured
+ *    (self.dino(imgs, is_training=True), P/src/model.py:782-783; hook P/src/dino_extraction.py:7-9).
+ *    imgs_dev       [B,3,crop,crop]
+ *    tokens_dev     [B,T,D]   final-LayerNorm'd tokens (cls | registers | patches), T = 1+R+n*n
+ *    qkv_last_dev   [B,T,3D]  may be NULL */
+int pio_vit_forward(pio_handle h, const float* imgs_dev, int32_t B, float* tokens_dev, float* qkv_last_dev,
+                    pio_stream stream);
+
+/* -- a4 + a5: CLS-row attention read-out and the two attention-weighted means
+ *    (process_self_attention, P/src/dino_extraction.py:24-34; P/src/model.py:867-872).
+ *    self_attn_dev [B,n*n]; head_maps_dev [B,H,n*n] (pre-softmax logits, may be NULL);
+ *    avg_token_dev [B,D] (may be NULL); disentangled_dev [B,H,D] (may be NULL). */
+int pio_cls_attention(pio_handle h, const float* qkv_last_dev, const float* tokens_dev, int32_t B,
+                      float* self_attn_dev, float* head_maps_dev, float* avg_token_dev,
+                      float* disentangled_dev, pio_stream stream);
+
+/* -- a6: traces -> count grids (map_traces_to_grid, P/src/bbox_utils.py:158-168).
+ *    xy_dev [P,2] float64 (x,y) of all points; offsets_dev [B+1] int32 CSR offsets; grids_dev [B,n,n]. */
+int pio_trace_grids(pio_handle h, const double* xy_dev, const int32_t* offsets_dev, int32_t B,
+                    int32_t total_points, float* grids_dev, pio_stream stream);
+
+/* -- a7 weights: per-box weight maps (extract_bboxes_feats, P/src/bbox_utils.py:8-109).
+ *    boxes_dev [B,NB,4] xywh already floor-divided by patch_size and truncated to int32;
+ *    mode 0 uniform, 1 gaussian (variance > 0), 2 centre one-hot (variance == 0; `center_choice_dev`
+ *    [B,NB,2] int32 gives the (y,x) picks for even spans, drawn by the host RNG like the reference's
+ *    random.choice), 3 attention-map slice (attn_dev [B,n*n] is renormalised IN PLACE per box, in box
+ *    order, as the reference does).
+ *    weights_dev [B,NB,n*n]: zero outside the box; empty boxes give NaN rows like the reference's mean
+ *    of an empty slice.  If single_map != 0 also produces the per-image normalised sum of maps
+ *    (get_single_embedding_per_image) in single_dev [B,n*n], skipping boxes whose components sum < 0. */
+int pio_bbox_weights(pio_handle h, const int32_t* boxes_dev, int32_t B, int32_t NB, int32_t mode, float variance,
+                     const int32_t* center_choice_dev, float* attn_dev, float* weights_dev,
+                     int32_t single_map, float* single_dev, pio_stream stream);
+
+/* -- a6/a7/a8 reduction: out[r,:] = scale * sum_p weights[r,p] * patch_tokens[img[r], p, :]
+ *    (P/src/model.py:1054; bbox_utils.py:53,79,109; model.py:90-92).
+ *    tokens_dev [B,T,D] as written by pio_vit_forward (patch rows start at 1+R);
+ *    weights_dev [R,n*n]; img_index_dev [R] int32 (NULL = row r uses image r); out_dev [R,D]. */
+int pio_region_reduce(pio_handle h, const float* tokens_dev, int32_t B, const float* weights_dev,
+                      const int32_t* img_index_dev, int32_t R, float scale, float* out_dev, pio_stream stream);
+
+/* -- a8: fixed whole-image weight map (compute_region_means, P/src/model.py:45-94), variance > 0.
+ *    map_dev [n*n]. variance >= 100 -> uniform. */
+int pio_gaussian_map(pio_handle h, float variance, float* map_dev, pio_stream stream);
+
+/* -- a9: memory projection (Im2TxtProjector.project, im2txtprojection.py:353-385), one pass over the bank
+ *    with an online softmax.  q_dev [N,D] is L2-normalised IN PLACE (reference line 368).
+ *    out_dev [N,D]; normalize != 0 L2-normalises the result; best_sims_dev [N,n_best] (may be NULL)
+ *    receives the n_best largest cosine similarities in descending order. */
+int pio_mem_project(pio_handle h, float* q_dev, int32_t N, float temperature, int32_t normalize,
+                    float* out_dev, int32_t n_best, float* best_sims_dev, pio_stream stream);
+
+/* -- a10: (x - b) @ A_pinv^T (revert_transformation, P/src/embedding_utils.py:17-25). x_dev [N,D] ->
+ *    out_dev [N,prefix_size]. */
+int pio_revert_transformation(pio_handle h, const float* x_dev, int32_t N, float* out_dev, pio_stream stream);
+
+/* -- a11 + a12: greedy decode (decoding_batched, P/src/decap/decap.py:116-155), KV-cached.
+ *    prefix_dev [N,prefix_size]; ids_dev [N,steps] int32; logprob_dev [N,steps] per-token
+ *    log-probabilities (may be NULL; the reference's score is exp of their row sum). */
+int pio_decode_greedy(pio_handle h, const float* prefix_dev, int32_t N, int32_t steps, int32_t* ids_dev,
+                      float* logprob_dev, pio_stream stream);
+
+/* Introspection used by the host mirror and the tests. */
+int pio_num_tokens(pio_handle h);     /* T */
+int pio_grid_side(pio_handle h);      /* n */
+int64_t pio_bank_rows(pio_handle h);
+
+/* Host-only (no GPU needed): the load-time position-grid interpolation of pio_finalize_weights
+ * (DINOv2 interpolate_pos_encoding: bicubic, antialias, offset 0).  pos [1+grid*grid, dim] -> out [1+n*n, dim]. */
+int pio_host_interpolate_pos_embed(const float* pos, int32_t grid, int32_t dim, int32_t n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PATCHIONER_HIP_H */

@@ -1,0 +1,639 @@
+// C ABI of libpatchioner_hip.so (see include/patchioner_hip.h): context, weight packing, launch plans.
+#include "../../include/patchioner_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+#include "host_prep.h"
+#include "kernels.h"
+
+using namespace pio;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_OK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess)                                                                         \
+      return fail(PIO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                \
+  } while (0)
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    return n;
+  }
+};
+
+struct VitLayerDev {
+  float *n1w, *n1b, *qkvb, *projb, *ls1, *n2w, *n2b, *fc1b, *fc2b, *ls2;
+  void *qkvw, *projw, *fc1w, *fc2w;
+};
+
+struct GraphKey {
+  int N, steps, lp;
+  bool operator<(const GraphKey& o) const {
+    if (N != o.N) return N < o.N;
+    if (steps != o.steps) return steps < o.steps;
+    return lp < o.lp;
+  }
+};
+
+}  // namespace
+
+struct pio_context {
+  pio_config cfg;
+  int n = 0, n2 = 0, T = 0, Tp = 0, Tk = 0, G = 0, D = 0, Kpe = 0, Kpad = 0, H = 0;
+  OperandType op = OP_F16;
+  bool finalized = false, has_vit = false, has_dec = false, has_inv = false;
+  std::unordered_map<std::string, HostTensor> host;
+  std::vector<void*> allocs;
+
+  // ViT weights
+  void* pe_w = nullptr; float* pe_b = nullptr; float* pos = nullptr; float* cls = nullptr; float* reg = nullptr;
+  float *norm_w = nullptr, *norm_b = nullptr;
+  std::vector<VitLayerDev> vl;
+  // ViT workspaces
+  float* x = nullptr; void* xn = nullptr; void* ao = nullptr; void* hbuf = nullptr; void* ape = nullptr;
+  void *q = nullptr, *k = nullptr, *vT = nullptr;
+  // read-out workspaces
+  float* head_logits = nullptr; float* head_sm = nullptr; int32_t* head_img = nullptr;
+  // decoder weights
+  float *clip_w = nullptr, *clip_b = nullptr, *wte = nullptr, *wpe = nullptr, *lnf_w = nullptr, *lnf_b = nullptr;
+  std::vector<DecLayerW> dl;
+  // decoder workspaces
+  float *dx = nullptr, *dy = nullptr, *dqkv = nullptr, *datt = nullptr, *dhid = nullptr, *kcache = nullptr,
+        *vcache = nullptr, *logits = nullptr, *prefix_buf = nullptr, *logprob_buf = nullptr;
+  int32_t* ids_buf = nullptr;
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  hipStream_t capture_stream = nullptr;
+  bool use_graph = true;
+  // inversion
+  float *A_pinv = nullptr, *inv_b = nullptr;
+  // memory bank
+  float* bank = nullptr; float* bank_inv = nullptr; int64_t bank_rows = 0; int bank_dim = 0;
+  float *part_acc = nullptr, *part_ml = nullptr, *sims = nullptr;
+  int parts = 256;
+
+  template <typename Tt>
+  int dmalloc(Tt** p, size_t count, bool zero = false) {
+    void* ptr = nullptr;
+    HIP_OK(hipMalloc(&ptr, count * sizeof(Tt) > 0 ? count * sizeof(Tt) : 16));
+    if (zero) HIP_OK(hipMemset(ptr, 0, count * sizeof(Tt)));
+    allocs.push_back(ptr);
+    *p = (Tt*)ptr;
+    return PIO_OK;
+  }
+  int dmalloc_bytes(void** p, size_t bytes, bool zero = false) {
+    HIP_OK(hipMalloc(p, bytes > 0 ? bytes : 16));
+    if (zero) HIP_OK(hipMemset(*p, 0, bytes));
+    allocs.push_back(*p);
+    return PIO_OK;
+  }
+};
+
+namespace {
+
+size_t op_size(OperandType) { return 2; }
+
+const HostTensor* find(pio_context* c, const std::string& key) {
+  auto it = c->host.find(key);
+  return it == c->host.end() ? nullptr : &it->second;
+}
+
+int need(pio_context* c, const std::string& key, std::vector<int64_t> shape, const HostTensor** out) {
+  const HostTensor* t = find(c, key);
+  if (!t) return fail(PIO_ERR_NOT_READY, "missing weight '" + key + "'");
+  int64_t want = 1;
+  for (auto s : shape) want *= s;
+  if (t->numel() != want) {
+    return fail(PIO_ERR_SHAPE, "weight '" + key + "' has " + std::to_string(t->numel()) + " elements, expected " +
+                                   std::to_string(want));
+  }
+  *out = t;
+  return PIO_OK;
+}
+
+int upload_f32(pio_context* c, const float* src, size_t count, float** dst) {
+  int rc = c->dmalloc(dst, count);
+  if (rc) return rc;
+  HIP_OK(hipMemcpy(*dst, src, count * sizeof(float), hipMemcpyHostToDevice));
+  return PIO_OK;
+}
+
+// fp32 [rows][cols] -> operand-precision [rows][cols_pad] (zero padded), uploaded
+int upload_op(pio_context* c, const float* src, int64_t rows, int64_t cols, int64_t cols_pad, void** dst) {
+  std::vector<uint16_t> tmp((size_t)rows * cols_pad, 0);
+  for (int64_t r = 0; r < rows; ++r) convert_row(c->op == OP_F16, src + r * cols, cols, tmp.data() + r * cols_pad);
+  int rc = c->dmalloc_bytes(dst, tmp.size() * 2);
+  if (rc) return rc;
+  HIP_OK(hipMemcpy(*dst, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+  return PIO_OK;
+}
+
+// Conv1D weight [in][out] -> [out][in] fp32, uploaded
+int upload_transposed(pio_context* c, const float* src, int64_t in, int64_t out, float** dst) {
+  std::vector<float> tmp((size_t)in * out);
+  for (int64_t i = 0; i < in; ++i)
+    for (int64_t o = 0; o < out; ++o) tmp[(size_t)o * in + i] = src[(size_t)i * out + o];
+  return upload_f32(c, tmp.data(), tmp.size(), dst);
+}
+
+int finalize_vit(pio_context* c) {
+  const int D = c->D, depth = c->cfg.depth, p = c->cfg.patch_size, R = c->cfg.num_registers;
+  const HostTensor* t;
+  int rc;
+  if ((rc = need(c, "patch_embed.proj.weight", {D, 3, p, p}, &t))) return rc;
+  if ((rc = upload_op(c, t->data.data(), D, c->Kpe, c->Kpad, &c->pe_w))) return rc;
+  if ((rc = need(c, "patch_embed.proj.bias", {D}, &t))) return rc;
+  if ((rc = upload_f32(c, t->data.data(), D, &c->pe_b))) return rc;
+  if ((rc = need(c, "cls_token", {D}, &t))) return rc;
+  if ((rc = upload_f32(c, t->data.data(), D, &c->cls))) return rc;
+  if (R > 0) {
+    if ((rc = need(c, "register_tokens", {R, D}, &t))) return rc;
+    if ((rc = upload_f32(c, t->data.data(), (size_t)R * D, &c->reg))) return rc;
+  }
+  const int g = c->cfg.pretrain_grid;
+  if ((rc = need(c, "pos_embed", {1 + (int64_t)g * g, D}, &t))) return rc;
+  {
+    std::vector<float> pos((size_t)(1 + c->n2) * D);
+    interpolate_pos_embed(t->data.data(), g, D, c->n, pos.data());
+    if ((rc = upload_f32(c, pos.data(), pos.size(), &c->pos))) return rc;
+  }
+  if ((rc = need(c, "norm.weight", {D}, &t))) return rc;
+  if ((rc = upload_f32(c, t->data.data(), D, &c->norm_w))) return rc;
+  if ((rc = need(c, "norm.bias", {D}, &t))) return rc;
+  if ((rc = upload_f32(c, t->data.data(), D, &c->norm_b))) return rc;
+  c->vl.resize(depth);
+  for (int l = 0; l < depth; ++l) {
+    VitLayerDev& L = c->vl[l];
+    const std::string pre = "blocks." + std::to_string(l) + ".";
+    struct F { const char* key; int64_t n; float** dst; };
+    F fs[] = {{"norm1.weight", D, &L.n1w}, {"norm1.bias", D, &L.n1b}, {"attn.qkv.bias", 3 * D, &L.qkvb},
+              {"attn.proj.bias", D, &L.projb}, {"ls1.gamma", D, &L.ls1}, {"norm2.weight", D, &L.n2w},
+              {"norm2.bias", D, &L.n2b}, {"mlp.fc1.bias", 4 * D, &L.fc1b}, {"mlp.fc2.bias", D, &L.fc2b},
+              {"ls2.gamma", D, &L.ls2}};
+    for (auto& f : fs) {
+      if ((rc = need(c, pre + f.key, {f.n}, &t))) return rc;
+      if ((rc = upload_f32(c, t->data.data(), f.n, f.dst))) return rc;
+    }
+    struct Wm { const char* key; int64_t rows, cols; void** dst; };
+    Wm ws[] = {{"attn.qkv.weight", 3 * D, D, &L.qkvw}, {"attn.proj.weight", D, D, &L.projw},
+               {"mlp.fc1.weight", 4 * D, D, &L.fc1w}, {"mlp.fc2.weight", D, 4 * D, &L.fc2w}};
+    for (auto& w : ws) {
+      if ((rc = need(c, pre + w.key, {w.rows, w.cols}, &t))) return rc;
+      if ((rc = upload_op(c, t->data.data(), w.rows, w.cols, w.cols, w.dst))) return rc;
+    }
+  }
+  // workspaces
+  const size_t B = c->cfg.max_batch, M = B * c->Tp;
+  if ((rc = c->dmalloc(&c->x, M * D, true))) return rc;
+  if ((rc = c->dmalloc_bytes(&c->xn, M * D * 2, true))) return rc;
+  if ((rc = c->dmalloc_bytes(&c->ao, M * D * 2, true))) return rc;
+  if ((rc = c->dmalloc_bytes(&c->hbuf, M * 4 * D * 2, true))) return rc;
+  if ((rc = c->dmalloc_bytes(&c->ape, B * c->n2 * c->Kpad * 2, true))) return rc;
+  const size_t qk = B * c->H * c->Tk * 64 * 2;
+  if ((rc = c->dmalloc_bytes(&c->q, qk, true))) return rc;
+  if ((rc = c->dmalloc_bytes(&c->k, qk, true))) return rc;
+  if ((rc = c->dmalloc_bytes(&c->vT, qk, true))) return rc;
+  const int Hr = c->cfg.readout_heads;
+  if ((rc = c->dmalloc(&c->head_logits, B * Hr * c->n2))) return rc;
+  if ((rc = c->dmalloc(&c->head_sm, B * Hr * c->n2))) return rc;
+  {
+    std::vector<int32_t> idx(B * Hr);
+    for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int32_t)(i / Hr);
+    if ((rc = c->dmalloc(&c->head_img, idx.size()))) return rc;
+    HIP_OK(hipMemcpy(c->head_img, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
+  }
+  c->has_vit = true;
+  return PIO_OK;
+}
+
+int finalize_decoder(pio_context* c) {
+  const int E = c->cfg.dec_embd, V = c->cfg.dec_vocab, P = c->cfg.dec_positions, L = c->cfg.dec_layers;
+  const int PS = c->cfg.prefix_size;
+  const HostTensor* t;
+  int rc;
+  if ((rc = need(c, "clip_project.model.0.weight", {E, PS}, &t))) return rc;
+  if ((rc = upload_f32(c, t->data.data(), (size_t)E * PS, &c->clip_w))) return rc;
+  if ((rc = need(c, "clip_project.model.0.bias", {E}, &t))) return rc;
+  if ((rc = upload_f32(c, t->data.data(), E, &c->clip_b))) return rc;
+  if ((rc = need(c, "decoder.transformer.wte.weight", {V, E}, &t))) return rc;
+  if ((rc = upload_f32(c, t->data.data(), (size_t)V * E, &c->wte))) return rc;
+  if ((rc = need(c, "decoder.transformer.wpe.weight", {P, E}, &t))) return rc;
+  if ((rc = upload_f32(c, t->data.data(), (size_t)P * E, &c->wpe))) return rc;
+  if ((rc = need(c, "decoder.transformer.ln_f.weight", {E}, &t))) return rc;
+  if ((rc = upload_f32(c, t->data.data(), E, &c->lnf_w))) return rc;
+  if ((rc = need(c, "decoder.transformer.ln_f.bias", {E}, &t))) return rc;
+  if ((rc = upload_f32(c, t->data.data(), E, &c->lnf_b))) return rc;
+  c->dl.resize(L);
+  for (int l = 0; l < L; ++l) {
+    DecLayerW& w = c->dl[l];
+    const std::string pre = "decoder.transformer.h." + std::to_string(l) + ".";
+    struct F { const char* key; int64_t n; const float** dst; };
+    F fs[] = {{"ln_1.weight", E, &w.ln1_w}, {"ln_1.bias", E, &w.ln1_b}, {"attn.c_attn.bias", 3 * E, &w.attn_b},
+              {"attn.c_proj.bias", E, &w.proj_b}, {"ln_2.weight", E, &w.ln2_w}, {"ln_2.bias", E, &w.ln2_b},
+              {"mlp.c_fc.bias", 4 * E, &w.fc_b}, {"mlp.c_proj.bias", E, &w.fc2_b}};
+    for (auto& f : fs) {
+      if ((rc = need(c, pre + f.key, {f.n}, &t))) return rc;
+      float* d;
+      if ((rc = upload_f32(c, t->data.data(), f.n, &d))) return rc;
+      *f.dst = d;
+    }
+    struct Wm { const char* key; int64_t in, out; const float** dst; };
+    Wm ws[] = {{"attn.c_attn.weight", E, 3 * E, &w.attn_w}, {"attn.c_proj.weight", E, E, &w.proj_w},
+               {"mlp.c_fc.weight", E, 4 * E, &w.fc_w}, {"mlp.c_proj.weight", 4 * E, E, &w.fc2_w}};
+    for (auto& m : ws) {
+      if ((rc = need(c, pre + m.key, {m.in, m.out}, &t))) return rc;
+      float* d;
+      if ((rc = upload_transposed(c, t->data.data(), m.in, m.out, &d))) return rc;
+      *m.dst = d;
+    }
+  }
+  const size_t N = c->cfg.max_prefixes, S = c->cfg.max_steps;
+  if ((rc = c->dmalloc(&c->dx, N * E, true))) return rc;
+  if ((rc = c->dmalloc(&c->dy, N * E, true))) return rc;
+  if ((rc = c->dmalloc(&c->dqkv, N * 3 * E, true))) return rc;
+  if ((rc = c->dmalloc(&c->datt, N * E, true))) return rc;
+  if ((rc = c->dmalloc(&c->dhid, N * 4 * E, true))) return rc;
+  if ((rc = c->dmalloc(&c->kcache, (size_t)L * N * S * E, true))) return rc;
+  if ((rc = c->dmalloc(&c->vcache, (size_t)L * N * S * E, true))) return rc;
+  if ((rc = c->dmalloc(&c->logits, N * V, true))) return rc;
+  if ((rc = c->dmalloc(&c->prefix_buf, N * PS, true))) return rc;
+  if ((rc = c->dmalloc(&c->logprob_buf, N * S, true))) return rc;
+  if ((rc = c->dmalloc(&c->ids_buf, N * S, true))) return rc;
+  c->has_dec = true;
+  return PIO_OK;
+}
+
+bool is_ignorable_key(const std::string& k) {
+  auto ends = [&](const char* s) { size_t n = strlen(s); return k.size() >= n && k.compare(k.size() - n, n, s) == 0; };
+  return k == "mask_token" || k == "decoder.lm_head.weight" || ends(".attn.bias") || ends(".attn.masked_bias");
+}
+
+bool is_known_key(const std::string& k) {
+  static const char* exact[] = {"cls_token", "pos_embed", "register_tokens", "patch_embed.proj.weight",
+                                "patch_embed.proj.bias", "norm.weight", "norm.bias", "talk2dino.A_pinv",
+                                "talk2dino.b"};
+  for (auto e : exact) if (k == e) return true;
+  return k.rfind("blocks.", 0) == 0 || k.rfind("decoder.transformer.", 0) == 0 || k.rfind("clip_project.model.0.", 0) == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pio_last_error(void) { return g_err.c_str(); }
+const char* pio_version(void) { return "patchioner_hip 0.1.0 (gfx950)"; }
+
+int pio_create(const pio_config* cfg, pio_handle* out) {
+  if (!cfg || !out) return fail(PIO_ERR_INVALID_ARG, "pio_create: null argument");
+  if (cfg->embed_dim % 64 != 0 || cfg->embed_dim / 64 != cfg->num_heads)
+    return fail(PIO_ERR_INVALID_ARG, "pio_create: backbone head_dim must be 64 (embed_dim = 64 * num_heads)");
+  if (cfg->crop_dim % cfg->patch_size != 0)
+    return fail(PIO_ERR_INVALID_ARG, "pio_create: crop_dim must be a multiple of patch_size");
+  if (cfg->max_batch < 1 || cfg->max_prefixes < 1 || cfg->max_prefixes > 128 || cfg->max_steps < 1 || cfg->max_steps > 64)
+    return fail(PIO_ERR_INVALID_ARG, "pio_create: capacities out of range (prefixes <= 128, steps <= 64)");
+  if (cfg->readout_heads != 16) return fail(PIO_ERR_INVALID_ARG, "pio_create: readout_heads must be 16");
+  int ndev = 0;
+  HIP_OK(hipGetDeviceCount(&ndev));
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(PIO_ERR_INVALID_ARG, "pio_create: no such HIP device");
+  HIP_OK(hipSetDevice(cfg->device));
+  pio_context* c = new pio_context();
+  c->cfg = *cfg;
+  c->D = cfg->embed_dim;
+  c->H = cfg->num_heads;
+  c->n = cfg->crop_dim / cfg->patch_size;
+  c->n2 = c->n * c->n;
+  c->G = 1 + cfg->num_registers;
+  c->T = c->G + c->n2;
+  c->Tp = round_up(c->T, 8);
+  c->Tk = round_up(c->T, 64);
+  c->Kpe = 3 * cfg->patch_size * cfg->patch_size;
+  c->Kpad = round_up(c->Kpe, 64);
+  c->op = cfg->vit_operand_type == 1 ? OP_BF16 : OP_F16;
+  const char* ng = getenv("PIO_NO_GRAPH");
+  c->use_graph = !(ng && ng[0] == '1');
+  hipError_t e = hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return fail(PIO_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+  *out = c;
+  return PIO_OK;
+}
+
+int pio_destroy(pio_handle c) {
+  if (!c) return PIO_OK;
+  hipSetDevice(c->cfg.device);
+  hipDeviceSynchronize();
+  for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
+  for (void* p : c->allocs) hipFree(p);
+  if (c->capture_stream) hipStreamDestroy(c->capture_stream);
+  delete c;
+  return PIO_OK;
+}
+
+int pio_load_weight(pio_handle c, const char* key, const float* host_data, const int64_t* shape, int32_t ndim) {
+  if (!c || !key || !host_data || (ndim > 0 && !shape)) return fail(PIO_ERR_INVALID_ARG, "pio_load_weight: null argument");
+  if (c->finalized) return fail(PIO_ERR_INVALID_ARG, "pio_load_weight: weights already finalized");
+  const std::string k(key);
+  if (is_ignorable_key(k)) return PIO_OK;
+  if (!is_known_key(k)) return fail(PIO_ERR_UNKNOWN_WEIGHT, "unknown weight key '" + k + "'");
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  t.data.assign(host_data, host_data + t.numel());
+  c->host[k] = std::move(t);
+  return PIO_OK;
+}
+
+int pio_finalize_weights(pio_handle c) {
+  if (!c) return fail(PIO_ERR_INVALID_ARG, "null handle");
+  if (c->finalized) return fail(PIO_ERR_INVALID_ARG, "pio_finalize_weights: called twice");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  int rc;
+  if (find(c, "cls_token")) {
+    if ((rc = finalize_vit(c))) return rc;
+  }
+  if (find(c, "decoder.transformer.wte.weight")) {
+    if ((rc = finalize_decoder(c))) return rc;
+  }
+  if (find(c, "talk2dino.A_pinv")) {
+    const HostTensor* t;
+    if ((rc = need(c, "talk2dino.A_pinv", {c->cfg.prefix_size, c->D}, &t))) return rc;
+    if ((rc = upload_f32(c, t->data.data(), t->data.size(), &c->A_pinv))) return rc;
+    if ((rc = need(c, "talk2dino.b", {c->D}, &t))) return rc;
+    if ((rc = upload_f32(c, t->data.data(), t->data.size(), &c->inv_b))) return rc;
+    c->has_inv = true;
+  }
+  c->host.clear();
+  c->finalized = true;
+  HIP_OK(hipDeviceSynchronize());
+  return PIO_OK;
+}
+
+static int bank_common(pio_context* c, int64_t rows, int32_t dim) {
+  c->bank_rows = rows;
+  c->bank_dim = dim;
+  int rc;
+  if ((rc = c->dmalloc(&c->bank_inv, (size_t)rows))) return rc;
+  HIP_OK(launch_row_inv_norm(c->bank, rows, dim, c->bank_inv, nullptr));
+  if ((rc = c->dmalloc(&c->part_acc, (size_t)c->parts * 16 * dim))) return rc;
+  if ((rc = c->dmalloc(&c->part_ml, (size_t)c->parts * 16 * 2))) return rc;
+  if ((rc = c->dmalloc(&c->sims, (size_t)16 * rows))) return rc;
+  HIP_OK(hipDeviceSynchronize());
+  return PIO_OK;
+}
+
+int pio_set_memory_bank(pio_handle c, const float* host_bank, int64_t rows, int32_t dim, int64_t* rows_kept) {
+  if (!c || !host_bank || rows < 1) return fail(PIO_ERR_INVALID_ARG, "pio_set_memory_bank: bad argument");
+  if (dim != 384 && dim != 512 && dim != 768) return fail(PIO_ERR_SHAPE, "memory bank dim must be 384, 512 or 768");
+  if (c->bank) return fail(PIO_ERR_INVALID_ARG, "memory bank already set");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  // the reference drops rows whose norm is 0 when it loads the bank (im2txtprojection.py:343-345)
+  std::vector<int64_t> keep;
+  keep.reserve(rows);
+  for (int64_t r = 0; r < rows; ++r) {
+    const float* p = host_bank + r * dim;
+    bool nz = false;
+    for (int d = 0; d < dim && !nz; ++d) nz = p[d] != 0.f;
+    if (nz) keep.push_back(r);
+  }
+  const int64_t kept = (int64_t)keep.size();
+  if (kept == 0) return fail(PIO_ERR_SHAPE, "memory bank has no non-zero row");
+  int rc;
+  if ((rc = c->dmalloc(&c->bank, (size_t)kept * dim))) return rc;
+  if (kept == rows) {
+    HIP_OK(hipMemcpy(c->bank, host_bank, (size_t)rows * dim * 4, hipMemcpyHostToDevice));
+  } else {
+    int64_t run_start = 0;   // copy maximal runs of consecutive kept rows
+    while (run_start < kept) {
+      int64_t run_end = run_start + 1;
+      while (run_end < kept && keep[run_end] == keep[run_end - 1] + 1) ++run_end;
+      HIP_OK(hipMemcpy(c->bank + run_start * dim, host_bank + keep[run_start] * dim,
+                       (size_t)(run_end - run_start) * dim * 4, hipMemcpyHostToDevice));
+      run_start = run_end;
+    }
+  }
+  if (rows_kept) *rows_kept = kept;
+  return bank_common(c, kept, dim);
+}
+
+int pio_set_memory_bank_device(pio_handle c, const float* dev_bank, int64_t rows, int32_t dim) {
+  if (!c || !dev_bank || rows < 1) return fail(PIO_ERR_INVALID_ARG, "pio_set_memory_bank_device: bad argument");
+  if (dim != 384 && dim != 512 && dim != 768) return fail(PIO_ERR_SHAPE, "memory bank dim must be 384, 512 or 768");
+  if (c->bank) return fail(PIO_ERR_INVALID_ARG, "memory bank already set");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  int rc;
+  if ((rc = c->dmalloc(&c->bank, (size_t)rows * dim))) return rc;
+  HIP_OK(hipMemcpy(c->bank, dev_bank, (size_t)rows * dim * 4, hipMemcpyDeviceToDevice));
+  return bank_common(c, rows, dim);
+}
+
+int pio_vit_forward(pio_handle c, const float* imgs, int32_t B, float* tokens, float* qkv_last, pio_stream stream) {
+  if (!c || !imgs || !tokens) return fail(PIO_ERR_INVALID_ARG, "pio_vit_forward: null argument");
+  if (!c->has_vit) return fail(PIO_ERR_NOT_READY, "pio_vit_forward: backbone weights not loaded");
+  if (B < 1 || B > c->cfg.max_batch) return fail(PIO_ERR_CAPACITY, "pio_vit_forward: batch above max_batch");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  const int D = c->D, M = B * c->Tp;
+  HIP_OK(launch_im2col(c->op, imgs, B, c->cfg.crop_dim, c->cfg.patch_size, c->n, c->Kpad, c->ape, s));
+  HIP_OK(launch_token_init(c->x, c->cls, c->pos, c->reg, B, c->cfg.num_registers, c->T, c->Tp, D, s));
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.T = c->T; g.Tp = c->Tp; g.Tk = c->Tk; g.G = c->G; g.n2 = c->n2; g.D = D; g.H = c->H;
+  g.x = c->x; g.pos = c->pos; g.q = c->q; g.k = c->k; g.vT = c->vT;
+  {
+    GemmArgs a = g;
+    a.A = c->ape; a.lda = c->Kpad; a.W = c->pe_w; a.bias = c->pe_b; a.M = B * c->n2; a.N = D; a.K = c->Kpad;
+    HIP_OK(launch_vit_gemm(c->op, EPI_PATCH_EMBED, a, s));
+  }
+  VitAttnArgs at;
+  at.q = c->q; at.k = c->k; at.vT = c->vT; at.out = c->ao; at.B = B; at.H = c->H; at.T = c->T; at.Tp = c->Tp;
+  at.Tk = c->Tk; at.D = D; at.scale = 0.125f;  // 64^-0.5
+  const int depth = c->cfg.depth;
+  for (int l = 0; l < depth; ++l) {
+    const VitLayerDev& L = c->vl[l];
+    HIP_OK(launch_layernorm(c->op, c->x, L.n1w, L.n1b, c->cfg.vit_ln_eps, M, D, c->xn, nullptr, c->T, c->Tp, s));
+    {
+      GemmArgs a = g;
+      a.A = c->xn; a.lda = D; a.W = L.qkvw; a.bias = L.qkvb; a.M = M; a.N = 3 * D; a.K = D;
+      a.qkv_last = (l == depth - 1) ? qkv_last : nullptr;
+      HIP_OK(launch_vit_gemm(c->op, EPI_QKV, a, s));
+    }
+    HIP_OK(launch_vit_attention(c->op, at, s));
+    {
+      GemmArgs a = g;
+      a.A = c->ao; a.lda = D; a.W = L.projw; a.bias = L.projb; a.ls = L.ls1; a.M = M; a.N = D; a.K = D;
+      HIP_OK(launch_vit_gemm(c->op, EPI_RESIDUAL, a, s));
+    }
+    HIP_OK(launch_layernorm(c->op, c->x, L.n2w, L.n2b, c->cfg.vit_ln_eps, M, D, c->xn, nullptr, c->T, c->Tp, s));
+    {
+      GemmArgs a = g;
+      a.A = c->xn; a.lda = D; a.W = L.fc1w; a.bias = L.fc1b; a.out16 = c->hbuf; a.M = M; a.N = 4 * D; a.K = D;
+      HIP_OK(launch_vit_gemm(c->op, EPI_GELU, a, s));
+    }
+    {
+      GemmArgs a = g;
+      a.A = c->hbuf; a.lda = 4 * D; a.W = L.fc2w; a.bias = L.fc2b; a.ls = L.ls2; a.M = M; a.N = D; a.K = 4 * D;
+      HIP_OK(launch_vit_gemm(c->op, EPI_RESIDUAL, a, s));
+    }
+  }
+  HIP_OK(launch_layernorm(c->op, c->x, c->norm_w, c->norm_b, c->cfg.vit_ln_eps, M, D, nullptr, tokens, c->T, c->Tp, s));
+  return PIO_OK;
+}
+
+int pio_cls_attention(pio_handle c, const float* qkv_last, const float* tokens, int32_t B, float* self_attn,
+                      float* head_maps, float* avg_token, float* disentangled, pio_stream stream) {
+  if (!c || !qkv_last || !self_attn) return fail(PIO_ERR_INVALID_ARG, "pio_cls_attention: null argument");
+  if (!c->has_vit) return fail(PIO_ERR_NOT_READY, "pio_cls_attention: backbone not loaded");
+  if (B < 1 || B > c->cfg.max_batch) return fail(PIO_ERR_CAPACITY, "pio_cls_attention: batch above max_batch");
+  if ((avg_token || disentangled) && !tokens) return fail(PIO_ERR_INVALID_ARG, "pio_cls_attention: tokens required");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  const int Hr = c->cfg.readout_heads;
+  float* hl = head_maps ? head_maps : (disentangled ? c->head_logits : nullptr);
+  HIP_OK(launch_cls_logits(qkv_last, B, c->T, c->G, c->D, Hr, c->cfg.readout_scale, self_attn, hl, s));
+  HIP_OK(launch_softmax_rows(self_attn, self_attn, B, c->n2, s));
+  if (avg_token)   // (self_attn[...,None] * patches).mean(1)
+    HIP_OK(launch_region_reduce(tokens, c->T, c->G, c->D, c->n2, self_attn, nullptr, B, 1.0f / c->n2, avg_token, s));
+  if (disentangled) {
+    HIP_OK(launch_softmax_rows(hl, c->head_sm, B * Hr, c->n2, s));
+    HIP_OK(launch_region_reduce(tokens, c->T, c->G, c->D, c->n2, c->head_sm, c->head_img, B * Hr, 1.0f / c->n2,
+                                disentangled, s));
+  }
+  return PIO_OK;
+}
+
+int pio_trace_grids(pio_handle c, const double* xy, const int32_t* offsets, int32_t B, int32_t total_points,
+                    float* grids, pio_stream stream) {
+  if (!c || !offsets || !grids || (total_points > 0 && !xy)) return fail(PIO_ERR_INVALID_ARG, "pio_trace_grids: null argument");
+  if (B < 1) return fail(PIO_ERR_INVALID_ARG, "pio_trace_grids: B < 1");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  HIP_OK(launch_trace_grids(xy, offsets, B, c->n, grids, (hipStream_t)stream));
+  return PIO_OK;
+}
+
+int pio_bbox_weights(pio_handle c, const int32_t* boxes, int32_t B, int32_t NB, int32_t mode, float variance,
+                     const int32_t* center_choice, float* attn, float* weights, int32_t single_map, float* single,
+                     pio_stream stream) {
+  if (!c || !boxes || !weights || (single_map && !single)) return fail(PIO_ERR_INVALID_ARG, "pio_bbox_weights: null argument");
+  if (B < 1 || NB < 1) return fail(PIO_ERR_INVALID_ARG, "pio_bbox_weights: empty batch");
+  if (mode < 0 || mode > 3) return fail(PIO_ERR_INVALID_ARG, "pio_bbox_weights: mode must be 0..3");
+  if (mode == 1 && !(variance > 0.f)) return fail(PIO_ERR_INVALID_ARG, "pio_bbox_weights: gaussian mode needs variance > 0");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  HIP_OK(launch_bbox_weights(boxes, B, NB, c->n, mode, variance, center_choice, attn, weights, single_map, single,
+                             (hipStream_t)stream));
+  return PIO_OK;
+}
+
+int pio_region_reduce(pio_handle c, const float* tokens, int32_t B, const float* weights, const int32_t* img_index,
+                      int32_t R, float scale, float* out, pio_stream stream) {
+  if (!c || !tokens || !weights || !out) return fail(PIO_ERR_INVALID_ARG, "pio_region_reduce: null argument");
+  if (R < 1 || B < 1) return fail(PIO_ERR_INVALID_ARG, "pio_region_reduce: empty input");
+  if (!img_index && R > B) return fail(PIO_ERR_INVALID_ARG, "pio_region_reduce: img_index required when R > B");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  HIP_OK(launch_region_reduce(tokens, c->T, c->G, c->D, c->n2, weights, img_index, R, scale, out, (hipStream_t)stream));
+  return PIO_OK;
+}
+
+int pio_gaussian_map(pio_handle c, float variance, float* map, pio_stream stream) {
+  if (!c || !map) return fail(PIO_ERR_INVALID_ARG, "pio_gaussian_map: null argument");
+  if (!(variance > 0.f)) return fail(PIO_ERR_INVALID_ARG, "pio_gaussian_map: variance must be > 0 (0 = host-drawn one-hot)");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  HIP_OK(launch_gaussian_map(c->n, variance, map, (hipStream_t)stream));
+  return PIO_OK;
+}
+
+int pio_mem_project(pio_handle c, float* q, int32_t N, float temperature, int32_t normalize, float* out,
+                    int32_t n_best, float* best_sims, pio_stream stream) {
+  if (!c || !q || !out) return fail(PIO_ERR_INVALID_ARG, "pio_mem_project: null argument");
+  if (!c->bank) return fail(PIO_ERR_NOT_READY, "pio_mem_project: memory bank not set");
+  if (N < 1) return fail(PIO_ERR_INVALID_ARG, "pio_mem_project: N < 1");
+  if (n_best < 0 || n_best > 16 || (n_best > 0 && !best_sims)) return fail(PIO_ERR_INVALID_ARG, "pio_mem_project: n_best must be 0..16");
+  if (!(temperature > 0.f)) return fail(PIO_ERR_INVALID_ARG, "pio_mem_project: temperature must be > 0");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  ProjectArgs a;
+  a.bank = c->bank; a.inv_norm = c->bank_inv; a.M = c->bank_rows; a.D = c->bank_dim; a.q = q; a.N = N;
+  a.temperature = temperature; a.normalize = normalize; a.out = out; a.n_best = n_best; a.best_sims = best_sims;
+  a.part_acc = c->part_acc; a.part_ml = c->part_ml; a.part_best = c->sims; a.parts = c->parts; a.n_best_cap = 16;
+  HIP_OK(launch_mem_project(a, (hipStream_t)stream));
+  return PIO_OK;
+}
+
+int pio_revert_transformation(pio_handle c, const float* x, int32_t N, float* out, pio_stream stream) {
+  if (!c || !x || !out || N < 1) return fail(PIO_ERR_INVALID_ARG, "pio_revert_transformation: bad argument");
+  if (!c->has_inv) return fail(PIO_ERR_NOT_READY, "pio_revert_transformation: talk2dino.A_pinv / talk2dino.b not loaded");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  HIP_OK(launch_revert(x, c->inv_b, c->A_pinv, N, c->D, c->cfg.prefix_size, out, (hipStream_t)stream));
+  return PIO_OK;
+}
+
+int pio_decode_greedy(pio_handle c, const float* prefix, int32_t N, int32_t steps, int32_t* ids, float* logprob,
+                      pio_stream stream) {
+  if (!c || !prefix || !ids) return fail(PIO_ERR_INVALID_ARG, "pio_decode_greedy: null argument");
+  if (!c->has_dec) return fail(PIO_ERR_NOT_READY, "pio_decode_greedy: decoder weights not loaded");
+  if (N < 1 || N > c->cfg.max_prefixes) return fail(PIO_ERR_CAPACITY, "pio_decode_greedy: N above max_prefixes");
+  if (steps < 1 || steps > c->cfg.max_steps) return fail(PIO_ERR_CAPACITY, "pio_decode_greedy: steps above max_steps");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  const int E = c->cfg.dec_embd, PS = c->cfg.prefix_size;
+  DecoderArgs a;
+  a.N = N; a.steps = steps; a.E = E; a.heads = c->cfg.dec_heads; a.layers = c->cfg.dec_layers; a.vocab = c->cfg.dec_vocab;
+  a.prefix_size = PS; a.eps = c->cfg.dec_ln_eps; a.prefix = c->prefix_buf; a.clip_w = c->clip_w; a.clip_b = c->clip_b;
+  a.wte = c->wte; a.wpe = c->wpe; a.lnf_w = c->lnf_w; a.lnf_b = c->lnf_b; a.layer = c->dl.data();
+  a.x = c->dx; a.y = c->dy; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.kcache = c->kcache; a.vcache = c->vcache;
+  a.max_steps = c->cfg.max_steps; a.logits = c->logits; a.ids = c->ids_buf; a.logprob = logprob ? c->logprob_buf : nullptr;
+  HIP_OK(hipMemcpyAsync(c->prefix_buf, prefix, (size_t)N * PS * 4, hipMemcpyDeviceToDevice, s));
+  if (c->use_graph) {
+    const GraphKey key{N, steps, logprob ? 1 : 0};
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+      hipGraph_t graph = nullptr;
+      HIP_OK(hipStreamBeginCapture(c->capture_stream, hipStreamCaptureModeThreadLocal));
+      hipError_t le = launch_decode_greedy(a, c->capture_stream);
+      hipError_t ce = hipStreamEndCapture(c->capture_stream, &graph);
+      if (le != hipSuccess) return fail(PIO_ERR_HIP, std::string("decode capture: ") + hipGetErrorString(le));
+      HIP_OK(ce);
+      hipGraphExec_t exec = nullptr;
+      HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      HIP_OK(hipGraphDestroy(graph));
+      it = c->graphs.emplace(key, exec).first;
+    }
+    HIP_OK(hipGraphLaunch(it->second, s));
+  } else {
+    HIP_OK(launch_decode_greedy(a, s));
+  }
+  HIP_OK(hipMemcpyAsync(ids, c->ids_buf, (size_t)N * steps * 4, hipMemcpyDeviceToDevice, s));
+  if (logprob) HIP_OK(hipMemcpyAsync(logprob, c->logprob_buf, (size_t)N * steps * 4, hipMemcpyDeviceToDevice, s));
+  return PIO_OK;
+}
+
+int pio_num_tokens(pio_handle c) { return c ? c->T : 0; }
+int pio_grid_side(pio_handle c) { return c ? c->n : 0; }
+int64_t pio_bank_rows(pio_handle c) { return c ? c->bank_rows : 0; }
+
+/* host-only helper exported for the CPU tests: DINOv2 interpolate_pos_encoding (bicubic, antialias) */
+int pio_host_interpolate_pos_embed(const float* pos, int32_t grid, int32_t dim, int32_t n, float* out) {
+  if (!pos || !out || grid < 1 || dim < 1 || n < 1) return fail(PIO_ERR_INVALID_ARG, "pio_host_interpolate_pos_embed: bad argument");
+  interpolate_pos_embed(pos, grid, dim, n, out);
+  return PIO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// Internal launch interface between api.cpp and the .hip kernel files.  Every launcher only enqueues
+// work on `stream` (no allocation, no synchronisation) and returns the hipError_t of the launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pio {
+
+enum OperandType { OP_F16 = 0, OP_BF16 = 1 };
+
+// ---------------------------------------------------------------------------------------------
+// ViT encoder
+// ---------------------------------------------------------------------------------------------
+enum GemmEpilogue {
+  EPI_PATCH_EMBED = 0,  // x[b*Tp + G + p][n]  = acc + bias[n] + pos[(1+p)][n]          (fp32)
+  EPI_QKV = 1,          // q/k [b][h][Tk][64], vT [b][h][64][Tk] (operand type) (+ fp32 qkv_last [B][T][3D])
+  EPI_RESIDUAL = 2,     // x[m][n] += ls[n] * (acc + bias[n])                            (fp32)
+  EPI_GELU = 3          // out16[m][n] = gelu_erf(acc + bias[n])                         (operand type)
+};
+
+struct GemmArgs {
+  const void* A;   // [M][lda] operand type, K contiguous
+  const void* W;   // [N][K]   operand type, K contiguous (torch Linear layout)
+  const float* bias;
+  int M, N, K, lda;
+  // epilogue operands
+  float* x;            // residual stream [B*Tp][D] fp32 (PATCH_EMBED, RESIDUAL)
+  const float* pos;    // interpolated position table [1+n2][D] (PATCH_EMBED)
+  const float* ls;     // LayerScale gamma [N] (RESIDUAL)
+  void* out16;         // GELU output [M][N]
+  void* q; void* k; void* vT;   // QKV outputs
+  float* qkv_last;     // optional fp32 capture [B][T][3D]
+  int T, Tp, Tk, G, n2, D, H;  // tokens / padded rows per image / padded key count / global tokens / patches
+};
+
+hipError_t launch_vit_gemm(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
+
+struct VitAttnArgs {
+  const void* q; const void* k; const void* vT;  // as written by EPI_QKV
+  void* out;       // [B*Tp][D] operand type
+  int B, H, T, Tp, Tk, D;
+  float scale;     // head_dim^-0.5
+};
+hipError_t launch_vit_attention(OperandType t, const VitAttnArgs& a, hipStream_t s);
+
+// LayerNorm rows of x [M][D] fp32 -> operand type (out16) or fp32 (out32; compacts Tp -> T rows per image)
+hipError_t launch_layernorm(OperandType t, const float* x, const float* w, const float* b, float eps, int M,
+                            int D, void* out16, float* out32, int T, int Tp, hipStream_t s);
+// imgs [B][3][S][S] fp32 -> patch rows [B*n2][Kpad] (k = c*p*p + py*p + px; columns >= 3*p*p stay zero)
+hipError_t launch_im2col(OperandType t, const float* imgs, int B, int S, int p, int n, int Kpad, void* out,
+                         hipStream_t s);
+// x[b][0] = cls + pos[0]; x[b][1..R] = registers; x[b][T..Tp-1] = 0
+hipError_t launch_token_init(float* x, const float* cls, const float* pos0, const float* reg, int B, int R, int T,
+                             int Tp, int D, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// attention read-out and region weighting (all fp32)
+// ---------------------------------------------------------------------------------------------
+// mean_logits [B][n2] = head-mean of (q_cls*scale).k_patch ; head_logits [B][Hr][n2] (may be null)
+hipError_t launch_cls_logits(const float* qkv_last, int B, int T, int G, int D, int Hr, float scale,
+                             float* mean_logits, float* head_logits, hipStream_t s);
+hipError_t launch_softmax_rows(const float* in, float* out, int rows, int n, hipStream_t s);
+hipError_t launch_trace_grids(const double* xy, const int32_t* offsets, int B, int n, float* grids, hipStream_t s);
+hipError_t launch_bbox_weights(const int32_t* boxes, int B, int NB, int n, int mode, float variance,
+                               const int32_t* center_choice, float* attn, float* weights, int single_map,
+                               float* single, hipStream_t s);
+hipError_t launch_region_reduce(const float* tokens, int T, int G, int D, int n2, const float* weights,
+                                const int32_t* img_index, int R, float scale, float* out, hipStream_t s);
+hipError_t launch_gaussian_map(int n, float variance, float* map, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// memory projection
+// ---------------------------------------------------------------------------------------------
+struct ProjectArgs {
+  const float* bank;      // [M][D] raw rows
+  const float* inv_norm;  // [M]
+  int64_t M; int D;
+  float* q;               // [N][D], normalised in place
+  int N;
+  float temperature;
+  int normalize;
+  float* out;             // [N][D]
+  int n_best; float* best_sims;
+  // workspaces (owned by the context)
+  float* part_acc;        // [parts][N][D]
+  float* part_ml;         // [parts][N][2]  (running max, running sum)
+  float* part_best;       // [parts][N][n_best_cap]
+  int parts; int n_best_cap;
+};
+hipError_t launch_mem_project(const ProjectArgs& a, hipStream_t s);
+hipError_t launch_row_inv_norm(const float* bank, int64_t M, int D, float* inv_norm, hipStream_t s);
+hipError_t launch_revert(const float* x, const float* b, const float* A_pinv, int N, int D, int P, float* out,
+                         hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// DeCap decoder (fp32, KV-cached greedy)
+// ---------------------------------------------------------------------------------------------
+struct DecLayerW {
+  const float *ln1_w, *ln1_b, *attn_w /*[3E][E]*/, *attn_b, *proj_w /*[E][E]*/, *proj_b;
+  const float *ln2_w, *ln2_b, *fc_w /*[4E][E]*/, *fc_b, *fc2_w /*[E][4E]*/, *fc2_b;
+};
+struct DecoderArgs {
+  int N, steps, E, heads, layers, vocab, prefix_size;
+  float eps;
+  const float* prefix;        // [N][prefix_size]
+  const float *clip_w /*[E][prefix]*/, *clip_b, *wte /*[V][E]*/, *wpe /*[P][E]*/, *lnf_w, *lnf_b;
+  const DecLayerW* layer;     // host array [layers]
+  // workspaces
+  float* x;      // [N][E] residual
+  float* y;      // [N][E] LayerNorm output
+  float* qkv;    // [N][3E]
+  float* att;    // [N][E]
+  float* hid;    // [N][4E]
+  float* kcache; // [layers][N][max_steps][E]
+  float* vcache;
+  int max_steps;
+  float* logits; // [N][V]
+  int32_t* ids;      // [N][steps]
+  float* logprob;    // [N][steps] or null
+};
+hipError_t launch_decode_greedy(const DecoderArgs& a, hipStream_t s);
+
+}  // namespace pio

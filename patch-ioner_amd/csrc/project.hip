@@ -1,0 +1,368 @@
+// Memory-bank projection: Im2TxtProjector.project (P/src/decap/im2txtprojection/im2txtprojection.py:353-385)
+// as ONE pass over the bank with an online softmax (the reference re-normalises the bank, takes
+// sim = q.bank_n^T, softmaxes sim/T and multiplies by the raw bank: three passes + a bank-sized temp).
+//
+//   sim[n][r]  = <q_n/|q_n|, bank[r]> * inv_norm[r]
+//   out[n][:]  = sum_r softmax_r(sim[n][r] / T) * bank[r][:]          (optionally L2-normalised)
+//
+// HBM-bound for <= 16 queries: the bank (M x D fp32, 1.8 GB for the COCO bank) is read exactly once.
+// All arithmetic is exact fp32 on v_mfma_f32_16x16x4_f32 (T = 0.01 multiplies cosine error by 100, so
+// reduced-precision operands are not used here).
+//
+// One 256-thread workgroup per CU walks a contiguous slab of rows in tiles of 16 rows, register-staged
+// into double-buffered LDS (row stride D*4+16 B => conflict-free for both access patterns below).  The 4
+// waves split D:  wave w owns channels [w*D/4, (w+1)*D/4).
+//   GEMM1  S[row][n]   partial over the wave's channels (A = bank rows, B = queries, both ds_read_b128),
+//          summed across the 4 waves through LDS (bitwise identical in every wave).
+//   online softmax     query n sits on lane&15, rows on (lane>>4, reg): tile max / sum = 4 regs + 2 shuffles.
+//   GEMM2  Acc[n][d] += P[row][n] * bank[row][d]: the S accumulator register t IS the A operand of the
+//          t-th MFMA when k-slot kq means row 4*kq+t, so P never moves; B = bank[4kq+t][d0+lane&15] (ds_read_b32).
+// Each workgroup ends with a partial (max, sum, Acc) that k_project_combine merges.
+#include "common.h"
+#include "kernels.h"
+
+namespace pio {
+
+static constexpr int PR_ROWS = 16;   // bank rows per tile
+static constexpr int PR_Q = 16;      // queries per pass
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// L2-normalise rows in place (reference line 368 mutates the caller's tensor)
+__global__ __launch_bounds__(256) void k_l2norm_rows(float* x, int D) {
+  __shared__ float red[4];
+  float* r = x + (size_t)blockIdx.x * D;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) s += r[i] * r[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float nrm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+  for (int i = threadIdx.x; i < D; i += 256) r[i] = r[i] / nrm;
+}
+
+__global__ __launch_bounds__(256) void k_row_inv_norm(const float* __restrict__ bank, int64_t M, int D, float* inv) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float4* r = (const float4*)(bank + row * D);
+  float s = 0.f;
+  for (int c = threadIdx.x & 63; c < (D >> 2); c += 64) {
+    const float4 v = r[c];
+    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) inv[row] = 1.0f / sqrtf(s);
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 1) void k_project(const float* __restrict__ bank, const float* __restrict__ inv_norm,
+                                                    int64_t M, const float* __restrict__ q, int N, int q0,
+                                                    float temperature, float* part_acc, float* part_ml, int parts) {
+  constexpr int STRIDE = D + 4;                  // floats; +16 B skews rows across the 64 banks
+  constexpr int DW = D / 4;                      // channels per wave
+  constexpr int NV = D / 4 * PR_ROWS / 256;      // float4 per thread per tile
+  static_assert(D % 64 == 0 && (D / 4 * PR_ROWS) % 256 == 0, "D");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* s_bank = lds;                            // [2][16][STRIDE]
+  float* s_q = lds + 2 * PR_ROWS * STRIDE;        // [16][STRIDE]
+  float* s_red = s_q + PR_Q * STRIDE;             // [4][256]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+
+  // slab of rows for this workgroup (multiple of 16 rows)
+  const int64_t tiles_total = (M + PR_ROWS - 1) / PR_ROWS;
+  const int64_t tiles_per = (tiles_total + parts - 1) / parts;
+  const int64_t t_begin = (int64_t)blockIdx.x * tiles_per;
+  int64_t t_end = t_begin + tiles_per;
+  if (t_end > tiles_total) t_end = tiles_total;
+
+  // queries -> LDS (zero rows for n >= N)
+  for (int i = tid; i < PR_Q * (D / 4); i += 256) {
+    const int n = i / (D / 4), c = i - n * (D / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q0 + n < N) v = ((const float4*)(q + (size_t)(q0 + n) * D))[c];
+    *(float4*)(s_q + n * STRIDE + 4 * c) = v;
+  }
+
+  float4 stage[NV];
+  auto load_tile = [&](int64_t t) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + 256 * i;
+      const int r = idx / (D / 4), c = idx - r * (D / 4);
+      int64_t row = t * PR_ROWS + r;
+      row = row < M ? row : M - 1;
+      stage[i] = ((const float4*)(bank + row * D))[c];
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + 256 * i;
+      const int r = idx / (D / 4), c = idx - r * (D / 4);
+      *(float4*)(s_bank + (buf * PR_ROWS + r) * STRIDE + 4 * c) = stage[i];
+    }
+  };
+
+  f32x4 acc[DW / 16];
+#pragma unroll
+  for (int j = 0; j < DW / 16; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;          // for query n = li (replicated over kq and over waves)
+
+  if (t_begin < t_end) {
+    load_tile(t_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int64_t t = t_begin; t < t_end; ++t) {
+    const int buf = (int)((t - t_begin) & 1);
+    if (t + 1 < t_end) load_tile(t + 1);
+    const float* sb = s_bank + buf * PR_ROWS * STRIDE;
+    // ---- GEMM1: partial S[row][n] over this wave's channels ----
+    f32x4 sp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < DW / 16; ++c) {
+      const int d = wid * DW + 16 * c + 4 * kq;
+      const float4 a = *(const float4*)(sb + li * STRIDE + d);
+      const float4 b = *(const float4*)(s_q + li * STRIDE + d);
+      sp = mfma16(a.x, b.x, sp);
+      sp = mfma16(a.y, b.y, sp);
+      sp = mfma16(a.z, b.z, sp);
+      sp = mfma16(a.w, b.w, sp);
+    }
+    *(f32x4*)(s_red + wid * 256 + lane * 4) = sp;
+    __syncthreads();
+    f32x4 sfull = *(const f32x4*)(s_red + lane * 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const f32x4 o = *(const f32x4*)(s_red + w * 256 + lane * 4);
+      sfull += o;
+    }
+    // ---- online softmax for query n = li; this lane's rows are 4*kq + i ----
+    float p[4];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t row = t * PR_ROWS + 4 * kq + i;
+      float z = -INFINITY;
+      if (row < M) z = (sfull[i] * inv_norm[row]) / temperature;
+      p[i] = z;
+      tmax = fmaxf(tmax, z);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);       // finite: every tile has at least one valid row
+    const float alpha = expf(m_run - m_new);      // exp(-inf) = 0 on the first tile
+    float rs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      p[i] = expf(p[i] - m_new);
+      rs += p[i];
+    }
+    rs += __shfl_xor(rs, 16);
+    rs += __shfl_xor(rs, 32);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+    // Acc[n][d]: this lane's register i belongs to query n = 4*kq + i -> fetch that query's alpha
+    float al[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) al[i] = __shfl(alpha, 4 * kq + i);
+    // ---- GEMM2: Acc[n][d] = Acc*alpha + P^T . bank ----
+#pragma unroll
+    for (int j = 0; j < DW / 16; ++j) {
+      f32x4 a4 = acc[j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a4[i] *= al[i];
+      const float* bp = sb + (4 * kq) * STRIDE + wid * DW + 16 * j + li;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) a4 = mfma16(p[tt], bp[tt * STRIDE], a4);
+      acc[j] = a4;
+    }
+    if (t + 1 < t_end) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- partial results: part_acc[block][n][D], part_ml[block][n][2] ----
+  float* pa = part_acc + (size_t)blockIdx.x * PR_Q * D;
+#pragma unroll
+  for (int j = 0; j < DW / 16; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pa[(size_t)(4 * kq + i) * D + wid * DW + 16 * j + li] = acc[j][i];
+  if (wid == 0 && kq == 0) {
+    part_ml[((size_t)blockIdx.x * PR_Q + li) * 2 + 0] = m_run;
+    part_ml[((size_t)blockIdx.x * PR_Q + li) * 2 + 1] = l_run;
+  }
+}
+
+// Merge the per-workgroup partials; one workgroup per query.
+__global__ __launch_bounds__(256) void k_project_combine(const float* __restrict__ part_acc,
+                                                         const float* __restrict__ part_ml, int parts, int D, int q0,
+                                                         int normalize, float* out) {
+  __shared__ float s_w[1024];
+  __shared__ float red[4];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  float mx = -INFINITY;
+  for (int b = tid; b < parts; b += 256) mx = fmaxf(mx, part_ml[((size_t)b * PR_Q + n) * 2]);
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float ls = 0.f;
+  for (int b = tid; b < parts; b += 256) {
+    const float mb = part_ml[((size_t)b * PR_Q + n) * 2];
+    const float w = (mb == -INFINITY) ? 0.f : expf(mb - mx);   // workgroups with an empty slab
+    s_w[b] = w;
+    ls += w * part_ml[((size_t)b * PR_Q + n) * 2 + 1];
+  }
+  ls = wave_sum(ls);
+  if ((tid & 63) == 0) red[tid >> 6] = ls;
+  __syncthreads();
+  const float inv_l = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+  __syncthreads();
+  float vals[4];
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int d = tid + 256 * k;
+    float a = 0.f;
+    if (d < D) {
+      for (int b = 0; b < parts; ++b) {
+        const float w = s_w[b];
+        if (w != 0.f) a += w * part_acc[((size_t)b * PR_Q + n) * D + d];
+      }
+      a *= inv_l;
+    }
+    vals[k] = a;
+    sq += a * a;
+  }
+  sq = wave_sum(sq);
+  if ((tid & 63) == 0) red[tid >> 6] = sq;
+  __syncthreads();
+  const float nrm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int d = tid + 256 * k;
+    if (d < D) out[(size_t)(q0 + n) * D + d] = normalize ? vals[k] / nrm : vals[k];
+  }
+}
+
+// Cosine similarities of 16 queries against every row + per-query top-k (return_n_best_sims path,
+// im2txtprojection.py:371-375, 382-383).  One wave per bank row; k <= 16.
+__global__ __launch_bounds__(256) void k_project_sims(const float* __restrict__ bank, const float* __restrict__ inv_norm,
+                                                      int64_t M, int D, const float* __restrict__ q, int N, float* sims) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* r = bank + row * D;
+  for (int n = 0; n < N; ++n) {
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += r[d] * q[(size_t)n * D + d];
+    s = wave_sum(s);
+    if (lane == 0) sims[(size_t)n * M + row] = s * inv_norm[row];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_topk_desc(const float* __restrict__ sims, int64_t M, int k, float* out) {
+  // one workgroup per query; k rounds of block-wide arg-max with exclusion (k is tiny)
+  __shared__ float s_v[4];
+  __shared__ long long s_i[4];
+  __shared__ long long taken[16];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float* r = sims + (size_t)n * M;
+  for (int round = 0; round < k; ++round) {
+    float bv = -INFINITY;
+    long long bi = -1;
+    for (int64_t i = tid; i < M; i += 256) {
+      bool used = false;
+      for (int u = 0; u < round; ++u) used |= (taken[u] == i);
+      const float v = r[i];
+      if (!used && (v > bv || bi < 0)) { bv = v; bi = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o);
+      const long long oi = __shfl_xor(bi, o);
+      if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { s_v[tid >> 6] = bv; s_i[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float fv = s_v[0]; long long fi = s_i[0];
+      for (int w = 1; w < 4; ++w)
+        if (s_i[w] >= 0 && (fi < 0 || s_v[w] > fv || (s_v[w] == fv && s_i[w] < fi))) { fv = s_v[w]; fi = s_i[w]; }
+      taken[round] = fi;
+      out[(size_t)n * k + round] = fv;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_revert(const float* __restrict__ x, const float* __restrict__ b,
+                                                const float* __restrict__ A, int D, int P, float* out) {
+  // out[n][p] = sum_d (x[n][d] - b[d]) * A_pinv[p][d]; one wave per output element
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), n = blockIdx.y;
+  if (p >= P) return;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) s += (x[(size_t)n * D + d] - b[d]) * A[(size_t)p * D + d];
+  s = wave_sum(s);
+  if (lane == 0) out[(size_t)n * P + p] = s;
+}
+
+template <int D>
+static hipError_t project_pass(const ProjectArgs& a, int q0, hipStream_t s) {
+  const int smem = (2 * PR_ROWS * (D + 4) + PR_Q * (D + 4) + 4 * 256) * (int)sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_project<D>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_project<D>), dim3(a.parts), dim3(256), smem, s, a.bank, a.inv_norm, a.M, a.q, a.N, q0,
+                     a.temperature, a.part_acc, a.part_ml, a.parts);
+  return hipGetLastError();
+}
+
+hipError_t launch_mem_project(const ProjectArgs& a, hipStream_t s) {
+  if (a.N <= 0 || a.M <= 0 || a.parts > 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_l2norm_rows, dim3(a.N), dim3(256), 0, s, a.q, a.D);
+  for (int q0 = 0; q0 < a.N; q0 += PR_Q) {
+    hipError_t e;
+    switch (a.D) {
+      case 384: e = project_pass<384>(a, q0, s); break;
+      case 512: e = project_pass<512>(a, q0, s); break;
+      case 768: e = project_pass<768>(a, q0, s); break;
+      default: return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+    const int nq = (a.N - q0) < PR_Q ? (a.N - q0) : PR_Q;
+    hipLaunchKernelGGL(k_project_combine, dim3(nq), dim3(256), 0, s, a.part_acc, a.part_ml, a.parts, a.D, q0,
+                       a.normalize, a.out);
+  }
+  if (a.n_best > 0) {
+    if (a.n_best > 16 || a.best_sims == nullptr || a.part_best == nullptr) return hipErrorInvalidValue;
+    for (int q0 = 0; q0 < a.N; q0 += PR_Q) {   // part_best is the [16][M] similarity scratch
+      const int nq = (a.N - q0) < PR_Q ? (a.N - q0) : PR_Q;
+      hipLaunchKernelGGL(k_project_sims, dim3((unsigned)((a.M + 3) / 4)), dim3(256), 0, s, a.bank, a.inv_norm, a.M, a.D,
+                         a.q + (size_t)q0 * a.D, nq, a.part_best);
+      hipLaunchKernelGGL(k_topk_desc, dim3(nq), dim3(256), 0, s, a.part_best, a.M, a.n_best,
+                         a.best_sims + (size_t)q0 * a.n_best);
+    }
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_row_inv_norm(const float* bank, int64_t M, int D, float* inv_norm, hipStream_t s) {
+  hipLaunchKernelGGL(k_row_inv_norm, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, bank, M, D, inv_norm);
+  return hipGetLastError();
+}
+
+hipError_t launch_revert(const float* x, const float* b, const float* A_pinv, int N, int D, int P, float* out,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(k_revert, dim3(ceil_div(P, 4), N), dim3(256), 0, s, x, b, A_pinv, D, P, out);
+  return hipGetLastError();
+}
+
+}  // namespace pio

@@ -1,0 +1,210 @@
+"""Thin python owner of one libpatchioner_hip handle: torch tensors in, torch tensors out.
+
+PyTorch here only provides device memory (tensors), the current stream and (in ``dist.py``)
+``torch.distributed``; every computation is a C-ABI call into the HIP library.  One Engine per process /
+GPU; not re-entrant (same as the reference, whose hooks write module-level globals,
+P/src/dino_extraction.py:7, P/src/model.py:30).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PioConfig, PioError, check, ptr
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Engine:
+    def __init__(self, *, embed_dim: int, depth: int, num_heads: int, num_registers: int, crop_dim: int,
+                 patch_size: int = 14, pretrain_grid: int = 37, prefix_size: int = 768, dec_layers: int = 4,
+                 dec_heads: int = 4, dec_embd: int = 768, dec_vocab: int = 50257, dec_positions: int = 1024,
+                 max_batch: int = 16, max_prefixes: int = 64, max_steps: int = 30, vit_dtype: str = "fp16",
+                 device_index: int = 0, readout_heads: int = 16, readout_scale: float = 0.125):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise PioError(-101, "no HIP device visible: the captioning path has no CPU fallback")
+        self.device = torch.device("cuda", device_index)
+        cfg = PioConfig(
+            embed_dim=embed_dim, depth=depth, num_heads=num_heads, patch_size=patch_size,
+            num_registers=num_registers, pretrain_grid=pretrain_grid, crop_dim=crop_dim, vit_ln_eps=1e-6,
+            readout_heads=readout_heads, readout_scale=readout_scale, dec_layers=dec_layers, dec_heads=dec_heads,
+            dec_embd=dec_embd, dec_vocab=dec_vocab, dec_positions=dec_positions, prefix_size=prefix_size,
+            dec_ln_eps=1e-5, max_batch=max_batch, max_prefixes=max_prefixes, max_steps=max_steps,
+            vit_operand_type={"fp16": 0, "bf16": 1}[vit_dtype], device=device_index)
+        self.cfg = cfg
+        h = ctypes.c_void_p()
+        check(self.lib.pio_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self.h = h
+        self.D, self.G = embed_dim, 1 + num_registers
+        self.n = self.lib.pio_grid_side(h)
+        self.T = self.lib.pio_num_tokens(h)
+        self.n2 = self.n * self.n
+        self.prefix_size = prefix_size
+        self.max_batch, self.max_prefixes, self.max_steps = max_batch, max_prefixes, max_steps
+        self.num_weights = 0
+        self.bank_rows = 0
+        self._finalized = False
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.pio_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False) -> List[str]:
+        """Upload fp32 tensors under their checkpoint keys; returns the keys the library does not know."""
+        unknown = []
+        for k, v in sd.items():
+            t = v.detach().to(dtype=torch.float32, device="cpu").contiguous()
+            shape = (ctypes.c_int64 * max(t.dim(), 1))(*t.shape)
+            rc = self.lib.pio_load_weight(self.h, k.encode(), ptr(t), shape, t.dim())
+            if rc == _lib.PIO_ERR_UNKNOWN_WEIGHT:
+                unknown.append(k)
+                continue
+            check(rc)
+            self.num_weights += t.numel()
+        if strict and unknown:
+            raise PioError(_lib.PIO_ERR_UNKNOWN_WEIGHT, "unexpected keys: %s" % unknown[:8])
+        return unknown
+
+    def finalize(self):
+        check(self.lib.pio_finalize_weights(self.h))
+        self._finalized = True
+
+    def set_memory_bank(self, bank: torch.Tensor) -> int:
+        bank = bank.detach().to(torch.float32).contiguous()
+        if bank.is_cuda:
+            check(self.lib.pio_set_memory_bank_device(self.h, ptr(bank), bank.shape[0], bank.shape[1]))
+        else:
+            kept = ctypes.c_int64(0)
+            check(self.lib.pio_set_memory_bank(self.h, ptr(bank), bank.shape[0], bank.shape[1], ctypes.byref(kept)))
+        self.bank_rows = int(self.lib.pio_bank_rows(self.h))
+        return self.bank_rows
+
+    # ------------------------------------------------------------------ a2/a3 backbone
+    def _dev(self, t: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def vit_forward(self, imgs: torch.Tensor, want_qkv: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        imgs = self._dev(imgs)
+        B = imgs.shape[0]
+        crop = self.cfg.crop_dim
+        if tuple(imgs.shape[1:]) != (3, crop, crop):
+            # the reference's reshape in process_self_attention fails for any other size
+            raise ValueError("images must be [B,3,%d,%d], got %s" % (crop, crop, tuple(imgs.shape)))
+        tokens = torch.empty(B, self.T, self.D, device=self.device, dtype=torch.float32)
+        qkv = torch.empty(B, self.T, 3 * self.D, device=self.device, dtype=torch.float32) if want_qkv else None
+        for s in range(0, B, self.max_batch):
+            e = min(B, s + self.max_batch)
+            check(self.lib.pio_vit_forward(self.h, ptr(imgs[s:e]), e - s, ptr(tokens[s:e]),
+                                           ptr(qkv[s:e]) if want_qkv else None, _stream()))
+        return tokens, qkv
+
+    # ------------------------------------------------------------------ a4/a5 read-out
+    def cls_attention(self, qkv: torch.Tensor, tokens: torch.Tensor, want_maps=False, want_avg=False,
+                      want_disentangled=False):
+        B = qkv.shape[0]
+        Hr = self.cfg.readout_heads
+        self_attn = torch.empty(B, self.n2, device=self.device, dtype=torch.float32)
+        maps = torch.empty(B, Hr, self.n2, device=self.device, dtype=torch.float32) if want_maps else None
+        avg = torch.empty(B, self.D, device=self.device, dtype=torch.float32) if want_avg else None
+        dis = torch.empty(B, Hr, self.D, device=self.device, dtype=torch.float32) if want_disentangled else None
+        for s in range(0, B, self.max_batch):
+            e = min(B, s + self.max_batch)
+            sl = slice(s, e)
+            check(self.lib.pio_cls_attention(
+                self.h, ptr(qkv[sl]), ptr(tokens[sl]), e - s, ptr(self_attn[sl]),
+                ptr(maps[sl]) if want_maps else None, ptr(avg[sl]) if want_avg else None,
+                ptr(dis[sl]) if want_disentangled else None, _stream()))
+        return self_attn, maps, avg, dis
+
+    # ------------------------------------------------------------------ a6 traces
+    def trace_grids(self, traces: Sequence[Sequence[dict]]) -> torch.Tensor:
+        B = len(traces)
+        offs = np.zeros(B + 1, dtype=np.int32)
+        pts = []
+        for i, tr in enumerate(traces):
+            for p in tr:
+                pts.append((float(p["x"]), float(p["y"])))
+            offs[i + 1] = len(pts)
+        xy = torch.tensor(pts, dtype=torch.float64).reshape(-1, 2) if pts else torch.zeros(0, 2, dtype=torch.float64)
+        xy_d = xy.to(self.device).contiguous()
+        offs_d = torch.from_numpy(offs).to(self.device)
+        grids = torch.empty(B, self.n, self.n, device=self.device, dtype=torch.float32)
+        check(self.lib.pio_trace_grids(self.h, ptr(xy_d) if len(pts) else None, ptr(offs_d), B, len(pts), ptr(grids),
+                                       _stream()))
+        return grids
+
+    # ------------------------------------------------------------------ a7 boxes
+    def bbox_weights(self, boxes_i32: torch.Tensor, mode: int, variance: float = 0.5,
+                     center_choice: Optional[torch.Tensor] = None, attn: Optional[torch.Tensor] = None,
+                     single_map: bool = False):
+        """boxes_i32 [B,NB,4] int32 (already // patch_size); returns (weights [B,NB,n2], single [B,n2] | None)."""
+        boxes_i32 = self._dev(boxes_i32, torch.int32)
+        B, NB = boxes_i32.shape[:2]
+        weights = torch.empty(B, NB, self.n2, device=self.device, dtype=torch.float32)
+        single = torch.empty(B, self.n2, device=self.device, dtype=torch.float32) if single_map else None
+        cc = self._dev(center_choice, torch.int32) if center_choice is not None else None
+        check(self.lib.pio_bbox_weights(self.h, ptr(boxes_i32), B, NB, mode, float(variance), ptr(cc), ptr(attn),
+                                        ptr(weights), 1 if single_map else 0, ptr(single), _stream()))
+        return weights, single
+
+    def region_reduce(self, tokens: torch.Tensor, weights: torch.Tensor, img_index: Optional[torch.Tensor],
+                      scale: float) -> torch.Tensor:
+        """out[r] = scale * sum_p weights[r,p] * patch_tokens[img_index[r], p]"""
+        weights = weights.reshape(-1, self.n2).contiguous()
+        R = weights.shape[0]
+        idx = self._dev(img_index, torch.int32) if img_index is not None else None
+        out = torch.empty(R, self.D, device=self.device, dtype=torch.float32)
+        check(self.lib.pio_region_reduce(self.h, ptr(tokens), tokens.shape[0], ptr(weights), ptr(idx), R, float(scale),
+                                         ptr(out), _stream()))
+        return out
+
+    def gaussian_map(self, variance: float) -> torch.Tensor:
+        m = torch.empty(self.n2, device=self.device, dtype=torch.float32)
+        check(self.lib.pio_gaussian_map(self.h, float(variance), ptr(m), _stream()))
+        return m
+
+    # ------------------------------------------------------------------ a9/a10 projection
+    def project(self, q: torch.Tensor, temperature: float = 0.01, normalize: bool = False,
+                n_best: Optional[int] = None):
+        """q [N,D] CUDA fp32 contiguous is L2-normalised IN PLACE (reference quirk)."""
+        assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous()
+        N = q.shape[0]
+        out = torch.empty(N, q.shape[1], device=self.device, dtype=torch.float32)
+        nb = int(n_best) if n_best else 0
+        best = torch.empty(N, nb, device=self.device, dtype=torch.float32) if nb else None
+        check(self.lib.pio_mem_project(self.h, ptr(q), N, float(temperature), 1 if normalize else 0, ptr(out), nb,
+                                       ptr(best), _stream()))
+        return (out, best) if nb else out
+
+    def revert_transformation(self, x: torch.Tensor) -> torch.Tensor:
+        x = self._dev(x)
+        out = torch.empty(x.shape[0], self.prefix_size, device=self.device, dtype=torch.float32)
+        check(self.lib.pio_revert_transformation(self.h, ptr(x), x.shape[0], ptr(out), _stream()))
+        return out
+
+    # ------------------------------------------------------------------ a11/a12 decoder
+    def decode_greedy(self, prefix: torch.Tensor, steps: int = 30, want_logprob: bool = False):
+        prefix = self._dev(prefix)
+        N = prefix.shape[0]
+        ids = torch.empty(N, steps, device=self.device, dtype=torch.int32)
+        lp = torch.empty(N, steps, device=self.device, dtype=torch.float32) if want_logprob else None
+        for s in range(0, N, self.max_prefixes):
+            e = min(N, s + self.max_prefixes)
+            check(self.lib.pio_decode_greedy(self.h, ptr(prefix[s:e]), e - s, steps, ptr(ids[s:e]),
+                                             ptr(lp[s:e]) if want_logprob else None, _stream()))
+        return ids, lp

@@ -1,0 +1,482 @@
+"""Host-side mirror of the reference ``Patchioner`` (P/src/model.py:96-1581) over the HIP engine.
+
+Same constructor keywords, ``from_config`` / ``forward`` / ``caption_tokens`` / ``caption_bboxes`` signatures,
+attributes (``image_transforms``, ``image_transforms_no_crop``, ``resize_dim``, ``crop_dim``, ``patch_size``,
+``num_tokens``, ``embed_dim`` ...) and output dictionary as the reference, so the ``eval-*-captioning``
+drivers run unchanged.  Everything numerical is a C-ABI call into libpatchioner_hip.so; there is no CPU
+path (constructing the model without a GPU or without the built library raises).
+
+Scope: the DINOv2(+registers) backbone with the DeCap / CapDec decoder head.  The other
+backbones and heads of the reference (ProxyCLIP, RegionCLIP, INViTE, DenseClip, AlphaClip, OpenCLIP, timm
+CLIP, DINO.txt, ViECap, MeaCap, ClipCap) raise ``NotImplementedError`` at construction.
+
+Build-specific config keys (there is no network on the target, so nothing is fetched from torch.hub / HF):
+  dino_weights     path (.pt/.pth state dict) or dict of the DINOv2 backbone weights
+  memory_bank      path (.npy / .pt / .h5) or tensor [M, D] of the text memory bank
+  synthetic_seed   int: synthesise any weights / bank not given (seeded; see weights.py)
+  max_batch, max_prefixes, vit_dtype ("fp16" | "bf16")
+"""
+from __future__ import annotations
+
+import math
+import os
+import random
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import yaml
+
+from . import weights as W
+from .engine import Engine
+from .preprocess import make_transforms, process_bboxes
+from .tokenizer import ClipDetokenizer
+
+_OUT_OF_SCOPE = ("proxyclip_clipmodel", "viecap_config", "regionclip_config", "invite_config", "denseclip_config",
+                 "alphaclip_config", "clipcap_config")
+
+
+def _load_state_dict(spec):
+    if spec is None:
+        return None
+    if isinstance(spec, dict):
+        return spec
+    if not os.path.exists(spec):
+        raise FileNotFoundError("checkpoint %r not found (no HuggingFace / torch.hub download on this target)" % (spec,))
+    sd = torch.load(spec, map_location="cpu")
+    return sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+
+
+def load_memory_bank(spec) -> torch.Tensor:
+    """[M, D] fp32 text-embedding bank (Im2TxtProjector._load_support_memory,
+    P/src/decap/im2txtprojection/im2txtprojection.py:387-407: HDF5 dataset '<name>-embeddings')."""
+    if isinstance(spec, torch.Tensor):
+        return spec.float()
+    if not os.path.exists(spec):
+        raise FileNotFoundError("memory bank %r not found" % (spec,))
+    if spec.endswith(".npy"):
+        import numpy as np
+        return torch.from_numpy(np.load(spec)).float()
+    if spec.endswith(".pt") or spec.endswith(".pth"):
+        return torch.load(spec, map_location="cpu").float()
+    if spec.endswith(".h5") or spec.endswith(".hdf5"):
+        try:
+            import h5py
+        except ImportError as e:  # pragma: no cover
+            raise ImportError("reading %r needs h5py (not installed); convert the bank to .npy" % spec) from e
+        with h5py.File(spec, "r") as hf:
+            names = [k for k in hf.keys() if k.endswith("-embeddings")]
+            if not names:
+                raise KeyError("no '<name>-embeddings' dataset in %r" % spec)
+            return torch.from_numpy(hf[names[0]][:]).float()
+    raise ValueError("unsupported memory bank format: %r" % (spec,))
+
+
+class Patchioner(nn.Module):
+
+    def __init__(self, decoder_weights, device, prefix_size, linear_talk2dino, support_memory_size, projection_type=None,
+                 dino_model=None, proxyclip_clipmodel=None, proxyclip_vfm=None, use_talk2dino_project=True, normalize=True,
+                 attention_type='qkv', talk2dino_config=None, talk2dino_weights=None, resize_dim=518, crop_dim=518,
+                 talk2dino_attn_type='qkv', calculate_argmax_text=False, online_texts=None, clip_model_name=None,
+                 use_open_clip=False, viecap_config=None, regionclip_config=None, invite_config=None,
+                 denseclip_config=None, alphaclip_config=None, clipcap_config=None, hf_repo_id=None,
+                 dino_weights=None, memory_bank=None, synthetic_seed=None, max_batch=16, max_prefixes=64,
+                 vit_dtype="fp16", **kwargs):
+        super().__init__(**kwargs)
+        given = dict(proxyclip_clipmodel=proxyclip_clipmodel, viecap_config=viecap_config,
+                     regionclip_config=regionclip_config, invite_config=invite_config,
+                     denseclip_config=denseclip_config, alphaclip_config=alphaclip_config,
+                     clipcap_config=clipcap_config)
+        for k in _OUT_OF_SCOPE:
+            if given[k] is not None:
+                raise NotImplementedError("%s: backbone/head outside the MI355X hot-path scope (DINOv2 + DeCap/CapDec)" % k)
+        if use_open_clip or online_texts is not None or calculate_argmax_text:
+            raise NotImplementedError("use_open_clip / online_texts / calculate_argmax_text need the CLIP text tower "
+                                      "or the bank's caption texts: outside the hot-path scope")
+        if dino_model is None or 'dinov2' not in dino_model or 'dinotxt' in dino_model:
+            raise ValueError("Unsupported backbone %r: this build implements the DINOv2 ViT-S/B/L-14 family" % (dino_model,))
+        if decoder_weights is None and synthetic_seed is None:
+            raise ValueError("decap_weights is required (or synthetic_seed for seeded synthetic weights)")
+        self.decoding_method = None
+        self.viecap = None
+        self.clipcap = None
+        self.calculate_argmax_text = False
+
+        # same validation order as the reference (P/src/model.py:144-162)
+        if projection_type in ('coco', 'msmarco', 'blip', 'vg', 'vg-test') or support_memory_size == 0:
+            pass
+        elif projection_type is not None and os.path.exists(projection_type):
+            pass
+        elif memory_bank is None and synthetic_seed is None:
+            raise Exception("The projection_type field must be 'coco', 'msmarco', 'blip' or 'vg'")
+
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("patchioner_amd runs on an MI355X only (device=%r): there is no CPU path; the CPU "
+                               "restatement used for parity lives in oracle/ and is test infrastructure" % (device,))
+        self._device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+
+        self.normalize = normalize
+        self.resize_dim = resize_dim
+        self.crop_dim = crop_dim
+        self.model_name = dino_model
+        self.num_global_tokens = 1 if "reg" not in dino_model else 5
+        patch_size = 14
+        if crop_dim % patch_size != 0:
+            raise ValueError("crop_dim must be a multiple of 14 (the reference's reshape fails otherwise)")
+        self.num_patch_tokens = crop_dim // patch_size * crop_dim // patch_size
+        self.num_tokens = self.num_global_tokens + self.num_patch_tokens
+        self.embed_dim, depth, heads = W.dino_arch(dino_model)
+        self.num_attn_heads = 16 if 'vits' not in dino_model else 6
+        if self.num_attn_heads != 16:
+            raise NotImplementedError("ViT-S read-out uses 6 heads in the reference; not built yet")
+        self.scale = 0.125
+        self.patch_size = patch_size
+        self.backbone_type = 'DINO'
+        self.image_transforms, self.image_transforms_no_crop = make_transforms(resize_dim, crop_dim)
+
+        vit_sd = _load_state_dict(dino_weights)
+        if vit_sd is None:
+            if synthetic_seed is None:
+                raise FileNotFoundError("dino_weights is required: torch.hub.load('facebookresearch/dinov2', ...) "
+                                        "needs network, which this target does not have")
+            vit_sd = W.synth_dinov2(synthetic_seed + 1, dino_model)
+        depth = 1 + max(int(k.split(".")[1]) for k in vit_sd if k.startswith("blocks."))
+        if attention_type != 'qkv':
+            # the reference re-orders the last block's fused q|k|v rows (P/src/model.py:569-582)
+            vit_sd = dict(vit_sd)
+            D = self.embed_dim
+            wk, bk = "blocks.%d.attn.qkv.weight" % (depth - 1), "blocks.%d.attn.qkv.bias" % (depth - 1)
+            ws = dict(zip("qkv", vit_sd[wk].reshape(3, D, D)))
+            bs = dict(zip("qkv", vit_sd[bk].reshape(3, D)))
+            vit_sd[wk] = torch.cat([ws[x] for x in attention_type], dim=0)
+            vit_sd[bk] = torch.cat([bs[x] for x in attention_type], dim=0)
+
+        dec_sd = _load_state_dict(decoder_weights)
+        if dec_sd is None:
+            dec_sd = W.synth_decap(synthetic_seed + 2, prefix_size)
+
+        self.embed_inversion = talk2dino_weights is not None
+        inv_sd = {}
+        if self.embed_inversion:
+            t2d = _load_state_dict(talk2dino_weights)
+            A = t2d["linear_layer.weight"].float()       # [dino_dim, clip_dim]
+            U, S, Vh = torch.linalg.svd(A, full_matrices=False)      # get_pseudo_inverse, embedding_utils.py:3-15
+            S_pinv = torch.zeros_like(S)
+            S_pinv[S > 1e-10] = 1.0 / S[S > 1e-10]
+            inv_sd["talk2dino.A_pinv"] = (Vh.T @ torch.diag(S_pinv) @ U.T).contiguous()
+            inv_sd["talk2dino.b"] = t2d["linear_layer.bias"].float()
+
+        self.engine = Engine(embed_dim=self.embed_dim, depth=depth, num_heads=heads,
+                             num_registers=self.num_global_tokens - 1, crop_dim=crop_dim, patch_size=patch_size,
+                             pretrain_grid=int(math.isqrt(vit_sd["pos_embed"].shape[1] - 1)), prefix_size=prefix_size,
+                             max_batch=max_batch, max_prefixes=max_prefixes, vit_dtype=vit_dtype,
+                             device_index=self._device.index)
+        self.engine.load_state_dict(vit_sd)
+        self.engine.load_state_dict(dec_sd)            # strict=False like the reference (decap.py:214)
+        if inv_sd:
+            self.engine.load_state_dict(inv_sd)
+        self.engine.finalize()
+
+        if support_memory_size > 0:
+            if memory_bank is not None:
+                bank = load_memory_bank(memory_bank)
+            elif synthetic_seed is not None:
+                bank = W.synth_bank(synthetic_seed + 3, support_memory_size, self.embed_dim)
+            else:
+                raise FileNotFoundError("support_memory_size > 0 needs `memory_bank` (path or tensor): building the "
+                                        "bank (CLIP text tower + datasets) is offline work outside this scope")
+            if 'dinov2' not in dino_model:      # normalize_memory_embs (P/src/model.py:174); never true here
+                bank = bank / bank.norm(dim=-1, keepdim=True)
+            self.engine.set_memory_bank(bank)
+            self.im_proj = self.engine
+        else:
+            self.im_proj = None
+        self.tokenizer = ClipDetokenizer()
+        self.last_ids = None
+        self.dino = self.engine     # callers test `model.dino is not None`
+        # one zero-size parameter so `next(model.parameters()).device` works as in the reference
+        self._anchor = nn.Parameter(torch.zeros(0, device=self._device), requires_grad=False)
+
+    # ------------------------------------------------------------------------------------------
+    @classmethod
+    def from_config(cls, config, device='cpu', online_texts=None):
+        if type(config) is str:
+            if os.path.exists(config):
+                with open(config, 'r') as f:
+                    config = yaml.safe_load(f)
+            else:
+                raise FileNotFoundError("config %r is not a local YAML file (HuggingFace download needs network)" % (config,))
+        model = cls(
+            projection_type=config.get('projection_type', 'coco'),
+            decoder_weights=config.get('decap_weights', None),
+            device=device,
+            prefix_size=config['prefix_size'],
+            linear_talk2dino=config.get('linear_talk2dino', False),
+            support_memory_size=config['support_memory_size'],
+            dino_model=config.get('dino_model', None),
+            proxyclip_clipmodel=config.get('proxyclip_clipmodel', None),
+            proxyclip_vfm=config.get('proxyclip_vfm', None),
+            use_talk2dino_project=config.get('use_talk2dino_project', True),
+            normalize=config.get('normalize', True),
+            attention_type=config.get('attention_type', 'qkv'),
+            talk2dino_config=config.get('talk2dino_config', None),
+            talk2dino_weights=config.get('talk2dino_weights', None),
+            resize_dim=config.get('resize_dim', 518),
+            crop_dim=config.get('crop_dim', 518),
+            talk2dino_attn_type=config.get('talk2dino_attn_type', 'qkv'),
+            calculate_argmax_text=config.get('calculate_argmax_text', False),
+            clip_model_name=config.get('clip_model_name', None),
+            online_texts=online_texts,
+            use_open_clip=config.get('use_open_clip', False),
+            viecap_config=config.get('viecap', None),
+            regionclip_config=config.get('regionclip_config', None),
+            invite_config=config.get('invite_config', None),
+            denseclip_config=config.get('denseclip_config', None),
+            alphaclip_config=config.get('alphaclip_config', None),
+            clipcap_config=config.get('clipcap', None),
+            hf_repo_id=config.get('hf_repo_id', None),
+            dino_weights=config.get('dino_weights', None),
+            memory_bank=config.get('memory_bank', None),
+            synthetic_seed=config.get('synthetic_seed', None),
+            max_batch=config.get('max_batch', 16),
+            max_prefixes=config.get('max_prefixes', 64),
+            vit_dtype=config.get('vit_dtype', 'fp16'),
+        )
+        model.to(device)
+        return model
+
+    def to(self, *args, **kwargs):
+        # weights live in the HIP library on the construction device; moving is a no-op (callers do
+        # model.to(device) with the same device, eval_trace_captioning.py:185)
+        return self
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, imgs,
+                get_cls_capt=True,
+                get_avg_self_attn_capt=False,
+                get_attn_heads_capt=False,
+                get_patch_capts=False,
+                get_register_capts=False,
+                bboxes=None,
+                traces=None,
+                get_controllable_capts=False,
+                bs_factor=4,
+                gaussian_avg=False,
+                gaussian_bbox_variance=0.5,
+                get_avg_patch_capt=False,
+                gaussian_img_variance=1,
+                use_attn_map_for_bboxes=False,
+                use_attention_tracing=False,
+                double_DINO_for_bboxes=False,
+                double_DINO_for_bboxes_return_type="avg",
+                double_DINO_use_cls=False,
+                cleaning_type=None,
+                clean_after_projection=True,
+                alpha=1.0,
+                clean_from="cls",
+                caption_bboxes_type: str = None,
+                return_n_best_sims=None,
+                compute_scores: bool = False
+                ):
+        assert clean_from in ["cls", "avg_self_attn"]
+        assert cleaning_type in [None, "orthogonal_projection", "contrastive_mask"]
+        if double_DINO_for_bboxes:
+            raise NotImplementedError("double_DINO_for_bboxes (extract_bboxes_feats_double_dino) is a 'next' row")
+        if cleaning_type is not None:
+            raise NotImplementedError("ctx_cleaner paths are a 'next' row (SURVEY 8f.4)")
+        if return_n_best_sims is not None:
+            raise NotImplementedError("return_n_best_sims is only usable with calculate_argmax_text in the reference")
+        if caption_bboxes_type is not None:
+            return self.caption_bboxes(imgs, bboxes, caption_bboxes_type, compute_scores=compute_scores)
+
+        eng = self.engine
+        outs = {}
+        bs = imgs.shape[0]
+        tokens, qkv = eng.vit_forward(imgs, want_qkv=True)
+        G = self.num_global_tokens
+        embed_dim = self.embed_dim
+        self_attn, _, avg_self_attn_token, disentangled_self_attn = eng.cls_attention(
+            qkv, tokens, want_maps=False, want_avg=get_avg_self_attn_capt, want_disentangled=get_attn_heads_capt)
+
+        def put(key, score_key, ret):
+            if compute_scores is True:
+                outs[key], outs[score_key] = ret
+            else:
+                outs[key] = ret
+
+        if get_cls_capt:
+            put('cls_capt', 'cls_capt_scores', self.caption_tokens(tokens[:, 0].contiguous(), compute_scores=compute_scores))
+        if get_avg_self_attn_capt:
+            put('avg_self_attn_capt', 'avg_self_attn_capt_scores',
+                self.caption_tokens(avg_self_attn_token, compute_scores=compute_scores))
+        if get_avg_patch_capt:
+            put('avg_patch_capt', 'avg_patch_capt_scores',
+                self.caption_tokens(self._region_means(tokens, gaussian_img_variance), compute_scores=compute_scores))
+        if get_attn_heads_capt:
+            ret = self.caption_tokens(disentangled_self_attn.view(-1, embed_dim), compute_scores=compute_scores)
+            H = self.num_attn_heads
+            caps = ret[0] if compute_scores is True else ret
+            outs['attn_heads_capts'] = [caps[i * H:(i + 1) * H] for i in range(bs)]
+            if compute_scores is True:
+                outs['attn_heads_scores'] = [ret[1][i * H:(i + 1) * H] for i in range(bs)]
+        if get_patch_capts:
+            n_patches = self.num_patch_tokens
+            ret = self.caption_tokens(tokens[:, G:].reshape(-1, embed_dim), project=True, compute_scores=compute_scores)
+            caps = ret[0] if compute_scores is True else ret
+            outs['patch_tokens_capts'] = [caps[i * n_patches:(i + 1) * n_patches] for i in range(bs)]
+            if compute_scores is True:
+                outs['patch_tokens_scores'] = [ret[1][i * n_patches:(i + 1) * n_patches] for i in range(bs)]
+        if get_register_capts:
+            ret = self.caption_tokens(tokens[:, 1:G].reshape(-1, embed_dim), compute_scores=compute_scores)
+            caps = ret[0] if compute_scores is True else ret
+            outs['register_capts'] = [caps[i * 4:(i + 1) * 4] for i in range(bs)]
+            if compute_scores is True:
+                outs['register_scores'] = [ret[1][i * 4:(i + 1) * 4] for i in range(bs)]
+
+        if bboxes is not None and not get_controllable_capts:
+            bbox_bs = bs * bs_factor
+            n_boxes = bboxes.shape[1]
+            bbox_feats = self._bbox_feats(tokens, bboxes, gaussian_avg, gaussian_bbox_variance, False,
+                                          self_attn if use_attn_map_for_bboxes else None).view(-1, embed_dim)
+            n_batch = math.ceil(bbox_feats.shape[0] / bbox_bs)
+            outs['bbox_capts'] = []
+            if compute_scores is True:
+                outs['bbox_scores'] = []
+            for i in range(n_batch):
+                start = i * bbox_bs
+                end = start + bbox_bs if i < n_batch - 1 else bbox_feats.shape[0]
+                ret = self.caption_tokens(bbox_feats[start:end], project=True, compute_scores=compute_scores)
+                if compute_scores is True:
+                    outs['bbox_capts'].extend(ret[0])
+                    outs['bbox_scores'].extend(ret[1])
+                else:
+                    outs['bbox_capts'].extend(ret)
+            outs['bbox_capts'] = [outs['bbox_capts'][i * n_boxes:(i + 1) * n_boxes] for i in range(bs)]
+            if compute_scores is True:
+                outs['bbox_scores'] = [outs['bbox_scores'][i * n_boxes:(i + 1) * n_boxes] for i in range(bs)]
+        elif bboxes is not None and get_controllable_capts:
+            bbox_feats = self._bbox_feats(tokens, bboxes, gaussian_avg, gaussian_bbox_variance, True,
+                                          self_attn if use_attn_map_for_bboxes else None)
+            outs['set_controllable_capts'] = self.caption_tokens(bbox_feats)
+
+        if traces is not None:
+            # map_traces_to_grid + (grid * patches).mean((1,2))  (P/src/model.py:1049-1054): mean over n*n cells
+            grids = eng.trace_grids(traces).view(bs, -1)
+            if use_attention_tracing:
+                grids = self_attn * grids
+            trace_embeds = eng.region_reduce(tokens, grids, None, 1.0 / self.num_patch_tokens)
+            outs['trace_capts'] = self.caption_tokens(trace_embeds)
+        return outs
+
+    # ------------------------------------------------------------------------------------------
+    def _region_means(self, tokens, variance):
+        """compute_region_means (P/src/model.py:45-94)."""
+        bs, eng = tokens.shape[0], self.engine
+        n = eng.n
+        if variance == 0:
+            opts = [n // 2] if n % 2 == 1 else [n // 2 - 1, n // 2]
+            wmap = torch.zeros(bs, n, n)
+            for i in range(bs):
+                cy = random.choice(opts)
+                cx = random.choice(opts)
+                wmap[i, cy, cx] = 1.0
+            wmap = wmap.view(bs, -1).to(eng.device)
+        else:
+            wmap = eng.gaussian_map(variance).unsqueeze(0).expand(bs, -1).contiguous()
+        return eng.region_reduce(tokens, wmap, None, 1.0)
+
+    def _center_choices(self, boxes_i, single):
+        """host draw of the var==0 centre cell, same RNG call order as bbox_utils.py:62-71"""
+        n = self.engine.n
+        B, NB = boxes_i.shape[:2]
+        out = torch.zeros(B, NB, 2, dtype=torch.int32)
+
+        def span(a, length):
+            lo, hi = slice(a, a + length + 1).indices(n)[:2]
+            return max(0, hi - lo)
+
+        bl = boxes_i.tolist()
+        for i in range(B):
+            for j in range(NB):
+                x1, y1, w, h = bl[i][j]
+                if single and x1 + y1 + w + h < 0:
+                    continue
+                hs, ws = span(y1, h), span(x1, w)
+                cy = [hs // 2] if hs % 2 == 1 else [hs // 2 - 1, hs // 2]
+                cx = [ws // 2] if ws % 2 == 1 else [ws // 2 - 1, ws // 2]
+                out[i, j, 0] = random.choice(cy)
+                out[i, j, 1] = random.choice(cx)
+        return out
+
+    def _bbox_feats(self, tokens, bboxes, gaussian_avg, variance, single, attention_map):
+        """extract_bboxes_feats (P/src/bbox_utils.py:8-109); `bboxes //= patch_size` mutates the caller's tensor."""
+        eng = self.engine
+        bboxes //= self.patch_size
+        boxes_i = bboxes.int().cpu()
+        B, NB = boxes_i.shape[:2]
+        cc = None
+        attn = None
+        if attention_map is not None:
+            mode = 3
+            attn = attention_map.clone()        # the reference hands a .cpu() copy, so the original map survives
+        elif gaussian_avg:
+            if variance == 0:
+                mode, cc = 2, self._center_choices(boxes_i, single)
+            else:
+                mode = 1
+        else:
+            mode = 0
+        weights, single_map = eng.bbox_weights(boxes_i, mode, variance, cc, attn, single_map=single)
+        if single:
+            return eng.region_reduce(tokens, single_map, None, 1.0)
+        idx = torch.arange(B, dtype=torch.int32).repeat_interleave(NB)
+        return eng.region_reduce(tokens, weights, idx, 1.0).view(B, NB, self.embed_dim)
+
+    # ------------------------------------------------------------------------------------------
+    def caption_bboxes(self, imgs, bboxes, capt_type='cls_capt', crop_boxes=False, compute_scores=False):
+        """P/src/model.py:1356-1390: crop each box from the PIL image and caption the crop."""
+        bs = len(imgs)
+        n_bboxes = bboxes.shape[1]
+        tf = self.image_transforms if crop_boxes else self.image_transforms_no_crop
+        crops = process_bboxes(imgs, bboxes, tf).to(self._device)
+        capts, scores = [], []
+        for i in range(n_bboxes):
+            start = i * bs
+            end = start + bs if i < n_bboxes - 1 else crops.shape[0]
+            out = self.forward(crops[start:end], get_cls_capt=capt_type == 'cls_capt',
+                               get_avg_self_attn_capt=capt_type == 'avg_self_attn_capt')
+            capts += out[capt_type]
+            if compute_scores:
+                scores += out[f"{capt_type}_scores"]
+        ret = {'bbox_capts': [capts[i * n_bboxes:(i + 1) * n_bboxes] for i in range(bs)]}
+        if compute_scores:
+            ret['bbox_scores'] = [scores[i * n_bboxes:(i + 1) * n_bboxes] for i in range(bs)]
+        return ret
+
+    def caption_tokens(self, dino_tokens, project=True, return_n_best_sims=None, compute_scores: bool = False):
+        """P/src/model.py:1392-1423."""
+        eng = self.engine
+        if self.im_proj is None:
+            project = False
+        x = dino_tokens
+        if not isinstance(x, torch.Tensor):
+            x = torch.tensor(x, dtype=torch.float)
+        xd = x.to(device=eng.device, dtype=torch.float32).contiguous()
+        if project:
+            prefix = eng.project(xd, normalize=self.normalize)
+            if isinstance(dino_tokens, torch.Tensor) and xd.data_ptr() != dino_tokens.data_ptr():
+                dino_tokens.copy_(xd)           # quirk: the query is L2-normalised in place (im2txtprojection.py:368)
+        else:
+            prefix = xd
+        if self.embed_inversion:
+            prefix = eng.revert_transformation(prefix)
+        ids, lp = eng.decode_greedy(prefix, steps=30, want_logprob=compute_scores)
+        self.last_ids = ids
+        outputs = self.tokenizer.batch_captions(ids.cpu().tolist(), decoding_method=self.decoding_method)
+        if compute_scores:
+            return outputs, torch.exp(lp.sum(dim=-1)).cpu().numpy().tolist()
+        return outputs
+
+    def __len__(self):
+        return self.engine.num_weights

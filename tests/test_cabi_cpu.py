@@ -1,0 +1,89 @@
+"""CPU-side checks of the C-ABI library: it builds, loads, exports every declared symbol, fails loudly
+without a GPU, and its host-only load-time code (position-grid interpolation) matches torch."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from patchioner_amd import build
+    build.build()
+    from patchioner_amd import _lib
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from patchioner_amd import _lib
+    header = open(os.path.join(ROOT, "include", "patchioner_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:const\s+char\*|int64_t|int)\s+(pio_\w+)\s*\(", header, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.pio_version()
+
+
+@pytest.mark.parametrize("n,D", [(16, 768), (8, 384), (37, 64), (20, 64)])
+def test_pos_embed_interpolation_matches_torch(lib, n, D):
+    g = 37
+    pos = torch.randn(1 + g * g, D, generator=torch.Generator().manual_seed(n))
+    out = torch.empty(1 + n * n, D)
+    rc = lib.pio_host_interpolate_pos_embed(pos.data_ptr(), g, D, n, out.data_ptr())
+    assert rc == 0
+    ref = torch.nn.functional.interpolate(pos[1:].reshape(1, g, g, D).permute(0, 3, 1, 2), size=(n, n),
+                                          mode="bicubic", antialias=True)
+    ref = torch.cat([pos[:1], ref.permute(0, 2, 3, 1).reshape(n * n, D)], 0)
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=2e-6)
+
+
+def test_invalid_arguments_fail_loudly(lib):
+    from patchioner_amd import _lib
+    assert lib.pio_host_interpolate_pos_embed(None, 37, 8, 4, None) == -1
+    assert b"bad argument" in lib.pio_last_error()
+    with pytest.raises(_lib.PioError):
+        _lib.check(lib.pio_create(None, None))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_cpu_fallback():
+    from patchioner_amd import Patchioner
+    from patchioner_amd._lib import PioError
+    from patchioner_amd.engine import Engine
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Patchioner.from_config({"prefix_size": 768, "support_memory_size": 0, "dino_model": "dinov2_vitb14_reg",
+                                "synthetic_seed": 0, "resize_dim": 224, "crop_dim": 224}, device="cpu")
+    with pytest.raises(PioError):
+        Engine(embed_dim=768, depth=2, num_heads=12, num_registers=4, crop_dim=224)
+
+
+def test_out_of_scope_options_raise():
+    from patchioner_amd import Patchioner
+    base = {"prefix_size": 768, "support_memory_size": 0, "synthetic_seed": 0}
+    with pytest.raises(NotImplementedError):
+        Patchioner.from_config(dict(base, dino_model="dinov2_vitb14_reg", viecap={"x": 1}), device="cuda")
+    with pytest.raises(ValueError):
+        Patchioner.from_config(dict(base, dino_model="vit_base_patch16_clip_224.openai"), device="cuda")
+    with pytest.raises(Exception, match="projection_type"):
+        Patchioner.from_config({"prefix_size": 768, "support_memory_size": 10, "decap_weights": "x.pt",
+                                "dino_model": "dinov2_vitb14_reg", "projection_type": "nonsense"}, device="cuda")
+
+
+def test_preprocess_and_bbox_adjust():
+    from PIL import Image
+    from patchioner_amd.preprocess import adjust_bbox_for_transform, make_transforms, process_bboxes
+    rng = np.random.RandomState(0)
+    img = Image.fromarray(rng.randint(0, 255, size=(300, 400, 3), dtype=np.uint8))
+    t, t_nc = make_transforms(224, 224)
+    a, b = t(img), t_nc(img)
+    assert a.shape == (3, 224, 224) and b.shape == (3, 224, 224) and a.dtype == torch.float32
+    box = adjust_bbox_for_transform(img, [100, 50, 120, 80], 224, 224)
+    assert 0 <= box[0] < 224 and 0 <= box[1] < 224 and box[0] + box[2] <= 224.0001
+    crops = process_bboxes([img], torch.tensor([[[10.0, 10.0, 50.0, 60.0], [0.0, 0.0, 100.0, 100.0]]]), t_nc)
+    assert crops.shape == (2, 3, 224, 224)
