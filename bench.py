@@ -1,0 +1,169 @@
+"""Headline benchmark: captions/s of the Patch-ioner hot path on MI355X (BASELINE.json config 2).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one Patchioner.forward over one batch of 16 synthetic 224x224 images with one 16-patch trace
+region per image (caption_from=patches): ViT-B/14-reg (12 layers) -> CLS-attention read-out -> trace grids
++ weighted mean -> memory projection against the 591 753 x 768 bank -> 30-step greedy decode -> id->string.
+Inputs are resident in HBM before the timed region.  Each rank runs the same per-GPU batch (weak scaling)
+and the ranks all-gather the token ids once per step (RCCL).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+BATCH = 16
+CROP = 224
+BANK_ROWS = 591753
+MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def build_model(device_index: int):
+    from patchioner_amd import Patchioner, weights as W
+    g = torch.Generator(device="cuda").manual_seed(6)
+    bank = torch.empty(BANK_ROWS, 768, device="cuda", dtype=torch.float32)
+    for s in range(0, BANK_ROWS, 65536):            # N(0,1) bank generated on the device (1.8 GB)
+        e = min(BANK_ROWS, s + 65536)
+        bank[s:e] = torch.randn(e - s, 768, device="cuda", generator=g)
+    cfg = {"decap_weights": W.synth_decap(3), "dino_weights": W.synth_dinov2(1), "memory_bank": bank,
+           "prefix_size": 768, "linear_talk2dino": False, "support_memory_size": BANK_ROWS,
+           "dino_model": "dinov2_vitb14_reg", "normalize": True, "resize_dim": CROP, "crop_dim": CROP,
+           "max_batch": BATCH, "max_prefixes": 64}
+    m = Patchioner.from_config(cfg, device="cuda:%d" % device_index)
+    del bank
+    torch.cuda.empty_cache()
+    return m
+
+
+def make_inputs():
+    import numpy as np
+    import golden_cases as gc
+    from patchioner_amd import weights as W
+    imgs = W.synth_images(1, BATCH, CROP).cuda()
+    rng = np.random.RandomState(2)
+    traces = [gc.block_trace(int(rng.randint(0, 13)), int(rng.randint(0, 13))) for _ in range(BATCH)]
+    return imgs, traces
+
+
+def cpu_baseline():
+    """The oracle (a port of the reference's algorithm: no KV cache, 3-pass projection, python loops) timed
+    on this box's host cores on ONE batch-16 step of the same workload with the full-size bank."""
+    import golden_cases as gc
+    import numpy as np
+    from oracle import patchioner_oracle as O
+    from patchioner_amd import weights as W
+    from patchioner_amd.tokenizer import ClipDetokenizer
+    torch.set_grad_enabled(False)
+    cores = torch.get_num_threads()
+    vit = O.DinoV2Oracle(W.synth_dinov2(1), num_heads=12)
+    dec = O.DeCapOracle(W.synth_decap(3))
+    bank = W.synth_bank(6, BANK_ROWS)
+    m = O.PatchionerOracle(vit, dec, bank, ClipDetokenizer().decode, crop_dim=CROP)
+    imgs = W.synth_images(1, BATCH, CROP)
+    rng = np.random.RandomState(2)
+    traces = [gc.block_trace(int(rng.randint(0, 13)), int(rng.randint(0, 13))) for _ in range(BATCH)]
+    m.forward(imgs[:2], get_cls_capt=False, traces=traces[:2])      # warm-up (thread pools, allocations)
+    t0 = time.perf_counter()
+    outs = m.forward(imgs, get_cls_capt=False, traces=traces)
+    dt = time.perf_counter() - t0
+    assert len(outs["trace_capts"]) == BATCH
+    return {"value": BATCH / dt, "unit": "captions/s", "cores": cores, "kind": "port",
+            "sample": "1 step of the same workload (batch 16, 224^2, 12-layer ViT-B/14, 591753x768 fp32 bank, "
+                      "30-step cache-less decode) on torch-CPU fp32, %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from patchioner_amd import dist as pdist
+    rank, world, local = pdist.init_from_env("nccl" if args.gpus > 1 else None)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    torch.set_grad_enabled(False)
+    import torch.distributed as dist
+
+    model = build_model(local)
+    imgs, traces = make_inputs()
+
+    def step():
+        outs = model(imgs, get_cls_capt=False, traces=traces, gaussian_avg=True)
+        ids = pdist.all_gather_equal_ids(model.last_ids)       # the path's only exchange: final captions' ids
+        return outs, ids
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    model.engine.profile_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs, ids = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = model.engine.profile_read()
+    model.engine.profile_enable(False)
+    assert len(outs["trace_capts"]) == BATCH and ids.shape[0] == BATCH * world
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        g = prof["vit_gemm"]
+        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")     # HBM bytes per launch from rocprofv3 --pmc passes
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("vit_gemm_hbm_bytes_per_launch")
+        stages = {}
+        for k, v in prof.items():
+            if v["launches"] == 0:
+                continue
+            sec = v["ms"] * 1e-3
+            stages[k] = {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
+                         "tflops": v["flops"] / sec / 1e12 if v["flops"] else None,
+                         "gbs": v["bytes"] / sec / 1e9 if v["bytes"] else None}
+        line = {
+            "metric": "captions/sec (whole node) + ms/image, ViT-B/14 224^2 bs16, 1/2/4/8 MI355X",
+            "value": BATCH * world * args.steps / dt, "unit": "captions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "ms_per_image": dt / args.steps * 1e3 / BATCH,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
+            "config": {"workload": "talk2dino_decap_COCO, ViT-B/14-reg 224^2, batch 16/GPU, caption_from=patches "
+                                   "(one 16-patch trace region per image), bank 591753x768 fp32, 30-step greedy decode",
+                       "global_batch": BATCH * world, "parallelism": "dp%d (image shards, ids all-gather)" % world},
+            "roofline": {"kernel": "k_vit_gemm (fp16 MFMA 32x32x16, 60+1 launches/step)", "bound": "mfma",
+                         "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "avg_launch_us": g["ms"] * 1e3 / max(g["launches"], 1)},
+            "stages": stages,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -165,6 +165,20 @@ int pio_revert_transformation(pio_handle h, const float* x_dev, int32_t N, float
 int pio_decode_greedy(pio_handle h, const float* prefix_dev, int32_t N, int32_t steps, int32_t* ids_dev,
                       float* logprob_dev, pio_stream stream);
 
+/* -- measurement: live HIP-event timing of the launches a call makes, on the stream they are launched on.
+ *    While enabled every bracketed launch records a (start, stop) event pair; pio_profile_read waits for the
+ *    recorded events of one class and returns the summed device time, the launch count and the ALGORITHMIC
+ *    flops / bytes of those launches (no padding, no recompute). */
+typedef enum {
+  PIO_PROF_VIT_GEMM = 0,     /* k_vit_gemm: patch-embed, qkv, proj, fc1, fc2 (flops) */
+  PIO_PROF_VIT_ATTN = 1,     /* k_vit_attention (flops) */
+  PIO_PROF_VIT_LN = 2,       /* k_layernorm (bytes) */
+  PIO_PROF_MEM_PROJECT = 3,  /* k_project + combine (bytes: one pass over the bank per 16 queries) */
+  PIO_PROF_DECODE = 4        /* the whole greedy-decode graph (bytes: all fp32 weights once per step) */
+} pio_profile_class;
+int pio_profile_enable(pio_handle h, int32_t on);   /* also clears previous records */
+int pio_profile_read(pio_handle h, int32_t cls, double* total_ms, int64_t* launches, double* flops, double* bytes);
+
 /* Introspection used by the host mirror and the tests. */
 int pio_num_tokens(pio_handle h);     /* T */
 int pio_grid_side(pio_handle h);      /* n */

@@ -34,6 +34,19 @@ int fail(int code, const std::string& msg) {
       return fail(PIO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                \
   } while (0)
 
+// Bracket `launch` with HIP events on its stream when profiling is on (class ids: pio_profile_class).
+#define PROF(c, cls_id, fl, by, stream, launch)                                                   \
+  do {                                                                                            \
+    hipEvent_t _a = nullptr, _b = nullptr;                                                        \
+    if ((c)->prof_on) { _a = (c)->next_event(); _b = (c)->next_event(); }                         \
+    if (_a && _b) HIP_OK(hipEventRecord(_a, (stream)));                                           \
+    HIP_OK(launch);                                                                               \
+    if (_a && _b) {                                                                               \
+      HIP_OK(hipEventRecord(_b, (stream)));                                                       \
+      (c)->prof.push_back({(cls_id), _a, _b, (double)(fl), (double)(by)});                        \
+    }                                                                                             \
+  } while (0)
+
 struct HostTensor {
   std::vector<float> data;
   std::vector<int64_t> shape;
@@ -93,6 +106,20 @@ struct pio_context {
   float* bank = nullptr; float* bank_inv = nullptr; int64_t bank_rows = 0; int bank_dim = 0;
   float *part_acc = nullptr, *part_ml = nullptr, *sims = nullptr;
   int parts = 256;
+  // live HIP-event profiling (pio_profile_*): one (start, stop) pair per bracketed launch
+  struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  hipEvent_t next_event() {
+    if (ev_used == ev_pool.size()) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      ev_pool.push_back(e);
+    }
+    return ev_pool[ev_used++];
+  }
 
   template <typename Tt>
   int dmalloc(Tt** p, size_t count, bool zero = false) {
@@ -341,11 +368,12 @@ int pio_create(const pio_config* cfg, pio_handle* out) {
 
 int pio_destroy(pio_handle c) {
   if (!c) return PIO_OK;
-  hipSetDevice(c->cfg.device);
-  hipDeviceSynchronize();
-  for (auto& g : c->graphs) hipGraphExecDestroy(g.second);
-  for (void* p : c->allocs) hipFree(p);
-  if (c->capture_stream) hipStreamDestroy(c->capture_stream);
+  (void)hipSetDevice(c->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
+  for (void* p : c->allocs) (void)hipFree(p);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->capture_stream) (void)hipStreamDestroy(c->capture_stream);
   delete c;
   return PIO_OK;
 }
@@ -453,6 +481,7 @@ int pio_vit_forward(pio_handle c, const float* imgs, int32_t B, float* tokens, f
   HIP_OK(hipSetDevice(c->cfg.device));
   hipStream_t s = (hipStream_t)stream;
   const int D = c->D, M = B * c->Tp;
+  const double Malg = (double)B * c->T;   // algorithmic rows: no pad tokens
   HIP_OK(launch_im2col(c->op, imgs, B, c->cfg.crop_dim, c->cfg.patch_size, c->n, c->Kpad, c->ape, s));
   HIP_OK(launch_token_init(c->x, c->cls, c->pos, c->reg, B, c->cfg.num_registers, c->T, c->Tp, D, s));
   GemmArgs g;
@@ -462,7 +491,7 @@ int pio_vit_forward(pio_handle c, const float* imgs, int32_t B, float* tokens, f
   {
     GemmArgs a = g;
     a.A = c->ape; a.lda = c->Kpad; a.W = c->pe_w; a.bias = c->pe_b; a.M = B * c->n2; a.N = D; a.K = c->Kpad;
-    HIP_OK(launch_vit_gemm(c->op, EPI_PATCH_EMBED, a, s));
+    PROF(c, PIO_PROF_VIT_GEMM, 2.0 * B * c->n2 * (double)D * c->Kpe, 0, s, launch_vit_gemm(c->op, EPI_PATCH_EMBED, a, s));
   }
   VitAttnArgs at;
   at.q = c->q; at.k = c->k; at.vT = c->vT; at.out = c->ao; at.B = B; at.H = c->H; at.T = c->T; at.Tp = c->Tp;
@@ -470,29 +499,31 @@ int pio_vit_forward(pio_handle c, const float* imgs, int32_t B, float* tokens, f
   const int depth = c->cfg.depth;
   for (int l = 0; l < depth; ++l) {
     const VitLayerDev& L = c->vl[l];
-    HIP_OK(launch_layernorm(c->op, c->x, L.n1w, L.n1b, c->cfg.vit_ln_eps, M, D, c->xn, nullptr, c->T, c->Tp, s));
+    PROF(c, PIO_PROF_VIT_LN, 0, Malg * D * 6.0, s,
+         launch_layernorm(c->op, c->x, L.n1w, L.n1b, c->cfg.vit_ln_eps, M, D, c->xn, nullptr, c->T, c->Tp, s));
     {
       GemmArgs a = g;
       a.A = c->xn; a.lda = D; a.W = L.qkvw; a.bias = L.qkvb; a.M = M; a.N = 3 * D; a.K = D;
       a.qkv_last = (l == depth - 1) ? qkv_last : nullptr;
-      HIP_OK(launch_vit_gemm(c->op, EPI_QKV, a, s));
+      PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * 3.0 * D * D, 0, s, launch_vit_gemm(c->op, EPI_QKV, a, s));
     }
-    HIP_OK(launch_vit_attention(c->op, at, s));
+    PROF(c, PIO_PROF_VIT_ATTN, 4.0 * B * (double)c->T * c->T * D, 0, s, launch_vit_attention(c->op, at, s));
     {
       GemmArgs a = g;
       a.A = c->ao; a.lda = D; a.W = L.projw; a.bias = L.projb; a.ls = L.ls1; a.M = M; a.N = D; a.K = D;
-      HIP_OK(launch_vit_gemm(c->op, EPI_RESIDUAL, a, s));
+      PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * D * D, 0, s, launch_vit_gemm(c->op, EPI_RESIDUAL, a, s));
     }
-    HIP_OK(launch_layernorm(c->op, c->x, L.n2w, L.n2b, c->cfg.vit_ln_eps, M, D, c->xn, nullptr, c->T, c->Tp, s));
+    PROF(c, PIO_PROF_VIT_LN, 0, Malg * D * 6.0, s,
+         launch_layernorm(c->op, c->x, L.n2w, L.n2b, c->cfg.vit_ln_eps, M, D, c->xn, nullptr, c->T, c->Tp, s));
     {
       GemmArgs a = g;
       a.A = c->xn; a.lda = D; a.W = L.fc1w; a.bias = L.fc1b; a.out16 = c->hbuf; a.M = M; a.N = 4 * D; a.K = D;
-      HIP_OK(launch_vit_gemm(c->op, EPI_GELU, a, s));
+      PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * 4.0 * D * D, 0, s, launch_vit_gemm(c->op, EPI_GELU, a, s));
     }
     {
       GemmArgs a = g;
       a.A = c->hbuf; a.lda = 4 * D; a.W = L.fc2w; a.bias = L.fc2b; a.ls = L.ls2; a.M = M; a.N = D; a.K = 4 * D;
-      HIP_OK(launch_vit_gemm(c->op, EPI_RESIDUAL, a, s));
+      PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * 4.0 * D * D, 0, s, launch_vit_gemm(c->op, EPI_RESIDUAL, a, s));
     }
   }
   HIP_OK(launch_layernorm(c->op, c->x, c->norm_w, c->norm_b, c->cfg.vit_ln_eps, M, D, nullptr, tokens, c->T, c->Tp, s));
@@ -573,7 +604,10 @@ int pio_mem_project(pio_handle c, float* q, int32_t N, float temperature, int32_
   a.bank = c->bank; a.inv_norm = c->bank_inv; a.M = c->bank_rows; a.D = c->bank_dim; a.q = q; a.N = N;
   a.temperature = temperature; a.normalize = normalize; a.out = out; a.n_best = n_best; a.best_sims = best_sims;
   a.part_acc = c->part_acc; a.part_ml = c->part_ml; a.part_best = c->sims; a.parts = c->parts; a.n_best_cap = 16;
-  HIP_OK(launch_mem_project(a, (hipStream_t)stream));
+  const double passes = (double)((N + 15) / 16);
+  PROF(c, PIO_PROF_MEM_PROJECT, 4.0 * N * (double)c->bank_rows * c->bank_dim,
+       passes * ((double)c->bank_rows * c->bank_dim * 4.0 + (double)c->bank_rows * 4.0), (hipStream_t)stream,
+       launch_mem_project(a, (hipStream_t)stream));
   return PIO_OK;
 }
 
@@ -601,6 +635,11 @@ int pio_decode_greedy(pio_handle c, const float* prefix, int32_t N, int32_t step
   a.x = c->dx; a.y = c->dy; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.kcache = c->kcache; a.vcache = c->vcache;
   a.max_steps = c->cfg.max_steps; a.logits = c->logits; a.ids = c->ids_buf; a.logprob = logprob ? c->logprob_buf : nullptr;
   HIP_OK(hipMemcpyAsync(c->prefix_buf, prefix, (size_t)N * PS * 4, hipMemcpyDeviceToDevice, s));
+  // algorithmic work of a KV-cached decode: per token 4 layers x 12 E^2 MACs + the tied LM head;
+  // bytes = every fp32 weight read once per step
+  const double layer_params = (double)c->cfg.dec_layers * 12.0 * E * E, head_params = (double)c->cfg.dec_vocab * E;
+  const double dec_flops = 2.0 * N * steps * (layer_params + head_params);
+  const double dec_bytes = 4.0 * steps * (layer_params + head_params);
   if (c->use_graph) {
     const GraphKey key{N, steps, logprob ? 1 : 0};
     auto it = c->graphs.find(key);
@@ -616,12 +655,37 @@ int pio_decode_greedy(pio_handle c, const float* prefix, int32_t N, int32_t step
       HIP_OK(hipGraphDestroy(graph));
       it = c->graphs.emplace(key, exec).first;
     }
-    HIP_OK(hipGraphLaunch(it->second, s));
+    PROF(c, PIO_PROF_DECODE, dec_flops, dec_bytes, s, hipGraphLaunch(it->second, s));
   } else {
-    HIP_OK(launch_decode_greedy(a, s));
+    PROF(c, PIO_PROF_DECODE, dec_flops, dec_bytes, s, launch_decode_greedy(a, s));
   }
   HIP_OK(hipMemcpyAsync(ids, c->ids_buf, (size_t)N * steps * 4, hipMemcpyDeviceToDevice, s));
   if (logprob) HIP_OK(hipMemcpyAsync(logprob, c->logprob_buf, (size_t)N * steps * 4, hipMemcpyDeviceToDevice, s));
+  return PIO_OK;
+}
+
+int pio_profile_enable(pio_handle c, int32_t on) {
+  if (!c) return fail(PIO_ERR_INVALID_ARG, "null handle");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  c->prof_on = on != 0;
+  c->prof.clear();
+  c->ev_used = 0;
+  return PIO_OK;
+}
+
+int pio_profile_read(pio_handle c, int32_t cls, double* total_ms, int64_t* launches, double* flops, double* bytes) {
+  if (!c || !total_ms || !launches || !flops || !bytes) return fail(PIO_ERR_INVALID_ARG, "pio_profile_read: null argument");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  double ms = 0, fl = 0, by = 0;
+  int64_t n = 0;
+  for (auto& r : c->prof) {
+    if (r.cls != cls) continue;
+    HIP_OK(hipEventSynchronize(r.b));
+    float t = 0.f;
+    HIP_OK(hipEventElapsedTime(&t, r.a, r.b));
+    ms += t; fl += r.flops; by += r.bytes; ++n;
+  }
+  *total_ms = ms; *launches = n; *flops = fl; *bytes = by;
   return PIO_OK;
 }
 

@@ -1,0 +1,93 @@
+"""Data-parallel captioning over the GPUs of one node: one process per GPU, images (and their regions)
+sharded, weights and memory bank replicated, ONE collective per batch -- an all-gather of the greedy
+token ids (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).
+
+The reference has no inference-time communication: images are independent units, so
+nothing on the data path needs an exchange; only the final captions are collected (~2 KB per rank and
+batch, latency-bound), once per batch and never per decode step.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torch.distributed.run environment; initialises the default
+    process group when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous shard [start, end) of `n_items` for `rank`; the first n_items % world ranks get one more."""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def shard_list(items: Sequence, world: int, rank: int):
+    s, e = shard_bounds(len(items), world, rank)
+    return items[s:e]
+
+
+def all_gather_ids(ids: torch.Tensor, group=None) -> torch.Tensor:
+    """ids [N_local, steps] int32 on this rank -> [N_total, steps] on every rank, rank-major order.
+    Ragged shards are padded to the largest shard for a single all-gather and trimmed afterwards."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return ids
+    world = dist.get_world_size(group)
+    n_local = torch.tensor([ids.shape[0]], dtype=torch.int64, device=ids.device)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    n_max = max(counts)
+    steps = ids.shape[1]
+    if all(c == n_max for c in counts):
+        out = torch.empty(world * n_max, steps, dtype=ids.dtype, device=ids.device)
+        dist.all_gather_into_tensor(out, ids.contiguous(), group=group)
+        return out
+    padded = torch.zeros(n_max, steps, dtype=ids.dtype, device=ids.device)
+    padded[: ids.shape[0]] = ids
+    out = torch.empty(world * n_max, steps, dtype=ids.dtype, device=ids.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return torch.cat([out[r * n_max: r * n_max + counts[r]] for r in range(world)], dim=0)
+
+
+def all_gather_equal_ids(ids: torch.Tensor, group=None) -> torch.Tensor:
+    """Fast path for equal shards (the benchmark's weak-scaling batches): one collective, no count exchange."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return ids
+    world = dist.get_world_size(group)
+    out = torch.empty(world * ids.shape[0], ids.shape[1], dtype=ids.dtype, device=ids.device)
+    dist.all_gather_into_tensor(out, ids.contiguous(), group=group)
+    return out
+
+
+def sharded_trace_captions(model, imgs: torch.Tensor, traces: Sequence, detokenize, group=None, **fwd) -> List[str]:
+    """Caption a global batch: every rank receives the same (imgs, traces), processes its contiguous shard
+    with `model(...)` and all ranks return the captions of the whole batch in the original order."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    s, e = shard_bounds(imgs.shape[0], world, rank)
+    steps = 30
+    if e > s:
+        model(imgs[s:e], get_cls_capt=False, traces=list(traces[s:e]), **fwd)
+        ids = model.last_ids
+    else:
+        ids = torch.zeros(0, steps, dtype=torch.int32, device=imgs.device)
+    all_ids = all_gather_ids(ids, group)
+    return detokenize(all_ids.cpu().tolist())

@@ -94,6 +94,21 @@ class Engine:
         self.bank_rows = int(self.lib.pio_bank_rows(self.h))
         return self.bank_rows
 
+    # ------------------------------------------------------------------ measurement
+    PROFILE_CLASSES = {"vit_gemm": 0, "vit_attention": 1, "vit_layernorm": 2, "mem_project": 3, "decode": 4}
+
+    def profile_enable(self, on: bool = True):
+        check(self.lib.pio_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self) -> Dict[str, dict]:
+        out = {}
+        for name, cls in self.PROFILE_CLASSES.items():
+            ms, n, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+            check(self.lib.pio_profile_read(self.h, cls, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl),
+                                            ctypes.byref(by)))
+            out[name] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+        return out
+
     # ------------------------------------------------------------------ a2/a3 backbone
     def _dev(self, t: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
         return t.to(device=self.device, dtype=dtype).contiguous()

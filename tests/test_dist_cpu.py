@@ -1,0 +1,82 @@
+"""The N>1 path on CPU: world_size-2 gloo processes exercising the shard bounds, the ragged / equal id
+all-gather and the sharded captioning driver (with a stand-in model: the HIP engine needs a GPU)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FakeModel:
+    """caption ids are a pure function of the image content, so any sharding must reproduce them"""
+
+    def __call__(self, imgs, get_cls_capt=False, traces=None, **kw):
+        base = (imgs.flatten(1).sum(1) * 7).round().to(torch.int32) % 1000
+        off = torch.tensor([len(t) for t in traces], dtype=torch.int32)
+        self.last_ids = (base + off)[:, None] + torch.arange(30, dtype=torch.int32)[None]
+        return {"trace_capts": ["x"] * imgs.shape[0]}
+
+
+def _worker(rank, world, port, n_imgs, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from patchioner_amd import dist as pdist
+    r, w, _ = pdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    # ragged gather
+    n_local = 3 + 2 * rank
+    ids = torch.full((n_local, 30), rank, dtype=torch.int32) + torch.arange(n_local, dtype=torch.int32)[:, None]
+    out = pdist.all_gather_ids(ids)
+    exp = torch.cat([torch.full((3 + 2 * k, 30), k, dtype=torch.int32) +
+                     torch.arange(3 + 2 * k, dtype=torch.int32)[:, None] for k in range(world)])
+    assert torch.equal(out, exp)
+    # equal-shard fast path
+    eq = pdist.all_gather_equal_ids(torch.full((4, 30), rank, dtype=torch.int32))
+    assert eq.shape == (4 * world, 30) and all(int(eq[4 * k, 0]) == k for k in range(world))
+    # sharded driver == single process
+    g = torch.Generator().manual_seed(0)
+    imgs = torch.randn(n_imgs, 3, 8, 8, generator=g)
+    traces = [[{"x": 0.5, "y": 0.5}] * (i % 4) for i in range(n_imgs)]
+    caps = pdist.sharded_trace_captions(_FakeModel(), imgs, traces, lambda ids: [tuple(r) for r in ids])
+    single = _FakeModel()
+    single(imgs, traces=traces)
+    assert caps == [tuple(r) for r in single.last_ids.tolist()]
+    if rank == 0:
+        q.put(len(caps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_imgs", [7, 1])
+def test_two_rank_gloo(n_imgs):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_imgs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) == n_imgs
+
+
+def test_shard_bounds():
+    from patchioner_amd.dist import shard_bounds
+    for n in (0, 1, 7, 16, 17):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1
