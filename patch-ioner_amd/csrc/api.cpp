@@ -95,7 +95,7 @@ struct pio_context {
   std::vector<DecLayerW> dl;
   // decoder workspaces
   float *dx = nullptr, *dy = nullptr, *dqkv = nullptr, *datt = nullptr, *dhid = nullptr, *kcache = nullptr,
-        *vcache = nullptr, *logits = nullptr, *prefix_buf = nullptr, *logprob_buf = nullptr;
+        *vcache = nullptr, *logits = nullptr, *dpart = nullptr, *prefix_buf = nullptr, *logprob_buf = nullptr;
   int32_t* ids_buf = nullptr;
   std::map<GraphKey, hipGraphExec_t> graphs;
   hipStream_t capture_stream = nullptr;
@@ -302,6 +302,7 @@ int finalize_decoder(pio_context* c) {
   if ((rc = c->dmalloc(&c->dqkv, N * 3 * E, true))) return rc;
   if ((rc = c->dmalloc(&c->datt, N * E, true))) return rc;
   if ((rc = c->dmalloc(&c->dhid, N * 4 * E, true))) return rc;
+  if ((rc = c->dmalloc(&c->dpart, 4 * N * E, true))) return rc;
   if ((rc = c->dmalloc(&c->kcache, (size_t)L * N * S * E, true))) return rc;
   if ((rc = c->dmalloc(&c->vcache, (size_t)L * N * S * E, true))) return rc;
   if ((rc = c->dmalloc(&c->logits, N * V, true))) return rc;
@@ -632,7 +633,7 @@ int pio_decode_greedy(pio_handle c, const float* prefix, int32_t N, int32_t step
   a.N = N; a.steps = steps; a.E = E; a.heads = c->cfg.dec_heads; a.layers = c->cfg.dec_layers; a.vocab = c->cfg.dec_vocab;
   a.prefix_size = PS; a.eps = c->cfg.dec_ln_eps; a.prefix = c->prefix_buf; a.clip_w = c->clip_w; a.clip_b = c->clip_b;
   a.wte = c->wte; a.wpe = c->wpe; a.lnf_w = c->lnf_w; a.lnf_b = c->lnf_b; a.layer = c->dl.data();
-  a.x = c->dx; a.y = c->dy; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.kcache = c->kcache; a.vcache = c->vcache;
+  a.x = c->dx; a.y = c->dy; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.part = c->dpart; a.kcache = c->kcache; a.vcache = c->vcache;
   a.max_steps = c->cfg.max_steps; a.logits = c->logits; a.ids = c->ids_buf; a.logprob = logprob ? c->logprob_buf : nullptr;
   HIP_OK(hipMemcpyAsync(c->prefix_buf, prefix, (size_t)N * PS * 4, hipMemcpyDeviceToDevice, s));
   // algorithmic work of a KV-cached decode: per token 4 layers x 12 E^2 MACs + the tied LM head;

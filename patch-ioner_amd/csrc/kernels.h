@@ -111,10 +111,11 @@ struct DecoderArgs {
   float* qkv;    // [N][3E]
   float* att;    // [N][E]
   float* hid;    // [N][4E]
+  float* part;   // [4][N][E] split-K partial sums of the residual branches
   float* kcache; // [layers][N][max_steps][E]
   float* vcache;
   int max_steps;
-  float* logits; // [N][V]
+  float* logits; // [ceil(V/16)][N][4] per-workgroup (max, arg-max, sum-exp) partials of the LM head
   int32_t* ids;      // [N][steps]
   float* logprob;    // [N][steps] or null
 };

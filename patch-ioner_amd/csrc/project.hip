@@ -86,25 +86,44 @@ __global__ __launch_bounds__(256, 1) void k_project(const float* __restrict__ ba
     *(float4*)(s_q + n * STRIDE + 4 * c) = v;
   }
 
-  float4 stage[NV];
-  auto load_tile = [&](int64_t t) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = tid + 256 * i;
-      const int r = idx / (D / 4), c = idx - r * (D / 4);
-      int64_t row = t * PR_ROWS + r;
-      row = row < M ? row : M - 1;
-      stage[i] = ((const float4*)(bank + row * D))[c];
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = tid + 256 * i;
-      const int r = idx / (D / 4), c = idx - r * (D / 4);
-      *(float4*)(s_bank + (buf * PR_ROWS + r) * STRIDE + 4 * c) = stage[i];
-    }
-  };
+  // Per-thread staging of the next tile: NV <= 12 float4 held in NAMED registers (hipcc keeps a staged
+  // array that is written in one loop and read in another in scratch).
+  static_assert(NV <= 12, "NV");
+  float4 g0, g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11;
+#define PIO_BANK_SRC(t, i) \
+  (((const float4*)(bank + (((t) * PR_ROWS + (tid + 256 * (i)) / (D / 4)) < M ? ((t) * PR_ROWS + (tid + 256 * (i)) / (D / 4)) : M - 1) * D))[(tid + 256 * (i)) % (D / 4)])
+#define PIO_BANK_DST(buf, i) \
+  (*(float4*)(s_bank + ((buf) * PR_ROWS + (tid + 256 * (i)) / (D / 4)) * STRIDE + 4 * ((tid + 256 * (i)) % (D / 4))))
+#define PIO_LOAD_BANK(t)                                  \
+  do {                                                    \
+    if constexpr (NV > 0) g0 = PIO_BANK_SRC(t, 0);        \
+    if constexpr (NV > 1) g1 = PIO_BANK_SRC(t, 1);        \
+    if constexpr (NV > 2) g2 = PIO_BANK_SRC(t, 2);        \
+    if constexpr (NV > 3) g3 = PIO_BANK_SRC(t, 3);        \
+    if constexpr (NV > 4) g4 = PIO_BANK_SRC(t, 4);        \
+    if constexpr (NV > 5) g5 = PIO_BANK_SRC(t, 5);        \
+    if constexpr (NV > 6) g6 = PIO_BANK_SRC(t, 6);        \
+    if constexpr (NV > 7) g7 = PIO_BANK_SRC(t, 7);        \
+    if constexpr (NV > 8) g8 = PIO_BANK_SRC(t, 8);        \
+    if constexpr (NV > 9) g9 = PIO_BANK_SRC(t, 9);        \
+    if constexpr (NV > 10) g10 = PIO_BANK_SRC(t, 10);     \
+    if constexpr (NV > 11) g11 = PIO_BANK_SRC(t, 11);     \
+  } while (0);
+#define PIO_STORE_BANK(buf)                               \
+  do {                                                    \
+    if constexpr (NV > 0) PIO_BANK_DST(buf, 0) = g0;      \
+    if constexpr (NV > 1) PIO_BANK_DST(buf, 1) = g1;      \
+    if constexpr (NV > 2) PIO_BANK_DST(buf, 2) = g2;      \
+    if constexpr (NV > 3) PIO_BANK_DST(buf, 3) = g3;      \
+    if constexpr (NV > 4) PIO_BANK_DST(buf, 4) = g4;      \
+    if constexpr (NV > 5) PIO_BANK_DST(buf, 5) = g5;      \
+    if constexpr (NV > 6) PIO_BANK_DST(buf, 6) = g6;      \
+    if constexpr (NV > 7) PIO_BANK_DST(buf, 7) = g7;      \
+    if constexpr (NV > 8) PIO_BANK_DST(buf, 8) = g8;      \
+    if constexpr (NV > 9) PIO_BANK_DST(buf, 9) = g9;      \
+    if constexpr (NV > 10) PIO_BANK_DST(buf, 10) = g10;   \
+    if constexpr (NV > 11) PIO_BANK_DST(buf, 11) = g11;   \
+  } while (0);
 
   f32x4 acc[DW / 16];
 #pragma unroll
@@ -112,13 +131,14 @@ __global__ __launch_bounds__(256, 1) void k_project(const float* __restrict__ ba
   float m_run = -INFINITY, l_run = 0.f;          // for query n = li (replicated over kq and over waves)
 
   if (t_begin < t_end) {
-    load_tile(t_begin);
-    store_tile(0);
+    PIO_LOAD_BANK(t_begin)
+    PIO_STORE_BANK(0)
   }
   __syncthreads();
   for (int64_t t = t_begin; t < t_end; ++t) {
     const int buf = (int)((t - t_begin) & 1);
-    if (t + 1 < t_end) load_tile(t + 1);
+    const int64_t tn = t + 1 < t_end ? t + 1 : t;   // last iteration: reload own tile, stored into the dead buffer
+    PIO_LOAD_BANK(tn)
     const float* sb = s_bank + buf * PR_ROWS * STRIDE;
     // ---- GEMM1: partial S[row][n] over this wave's channels ----
     f32x4 sp = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -180,9 +200,13 @@ __global__ __launch_bounds__(256, 1) void k_project(const float* __restrict__ ba
       for (int tt = 0; tt < 4; ++tt) a4 = mfma16(p[tt], bp[tt * STRIDE], a4);
       acc[j] = a4;
     }
-    if (t + 1 < t_end) store_tile(buf ^ 1);
+    PIO_STORE_BANK(buf ^ 1)
     __syncthreads();
   }
+#undef PIO_LOAD_BANK
+#undef PIO_STORE_BANK
+#undef PIO_BANK_SRC
+#undef PIO_BANK_DST
 
   // ---- partial results: part_acc[block][n][D], part_ml[block][n][2] ----
   float* pa = part_acc + (size_t)blockIdx.x * PR_Q * D;
@@ -196,17 +220,19 @@ __global__ __launch_bounds__(256, 1) void k_project(const float* __restrict__ ba
   }
 }
 
-// Merge the per-workgroup partials; one workgroup per query.
+// Merge the per-workgroup partials: out[n][d] = sum_b e^{m_b - M} acc_b[n][d] / sum_b e^{m_b - M} l_b.
+// One workgroup per (query, 64 channels): lane = channel, the 4 waves split the partials.
 __global__ __launch_bounds__(256) void k_project_combine(const float* __restrict__ part_acc,
                                                          const float* __restrict__ part_ml, int parts, int D, int q0,
-                                                         int normalize, float* out) {
+                                                         float* out) {
   __shared__ float s_w[1024];
   __shared__ float red[4];
-  const int n = blockIdx.x, tid = threadIdx.x;
+  __shared__ float s_acc[4][64];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   float mx = -INFINITY;
   for (int b = tid; b < parts; b += 256) mx = fmaxf(mx, part_ml[((size_t)b * PR_Q + n) * 2]);
   mx = wave_max(mx);
-  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  if (lane == 0) red[wid] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   __syncthreads();
@@ -218,35 +244,16 @@ __global__ __launch_bounds__(256) void k_project_combine(const float* __restrict
     ls += w * part_ml[((size_t)b * PR_Q + n) * 2 + 1];
   }
   ls = wave_sum(ls);
-  if ((tid & 63) == 0) red[tid >> 6] = ls;
+  if (lane == 0) red[wid] = ls;
   __syncthreads();
   const float inv_l = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+  const int d = blockIdx.y * 64 + lane;
+  float a = 0.f;
+#pragma unroll 8
+  for (int b = wid; b < parts; b += 4) a += s_w[b] * part_acc[((size_t)b * PR_Q + n) * D + d];
+  s_acc[wid][lane] = a;
   __syncthreads();
-  float vals[4];
-  float sq = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int d = tid + 256 * k;
-    float a = 0.f;
-    if (d < D) {
-      for (int b = 0; b < parts; ++b) {
-        const float w = s_w[b];
-        if (w != 0.f) a += w * part_acc[((size_t)b * PR_Q + n) * D + d];
-      }
-      a *= inv_l;
-    }
-    vals[k] = a;
-    sq += a * a;
-  }
-  sq = wave_sum(sq);
-  if ((tid & 63) == 0) red[tid >> 6] = sq;
-  __syncthreads();
-  const float nrm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int d = tid + 256 * k;
-    if (d < D) out[(size_t)(q0 + n) * D + d] = normalize ? vals[k] / nrm : vals[k];
-  }
+  if (wid == 0) out[(size_t)(q0 + n) * D + d] = ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane])) * inv_l;
 }
 
 // Cosine similarities of 16 queries against every row + per-query top-k (return_n_best_sims path,
@@ -338,9 +345,10 @@ hipError_t launch_mem_project(const ProjectArgs& a, hipStream_t s) {
     }
     if (e != hipSuccess) return e;
     const int nq = (a.N - q0) < PR_Q ? (a.N - q0) : PR_Q;
-    hipLaunchKernelGGL(k_project_combine, dim3(nq), dim3(256), 0, s, a.part_acc, a.part_ml, a.parts, a.D, q0,
-                       a.normalize, a.out);
+    hipLaunchKernelGGL(k_project_combine, dim3(nq, a.D / 64), dim3(256), 0, s, a.part_acc, a.part_ml, a.parts, a.D,
+                       q0, a.out);
   }
+  if (a.normalize) hipLaunchKernelGGL(k_l2norm_rows, dim3(a.N), dim3(256), 0, s, a.out, a.D);
   if (a.n_best > 0) {
     if (a.n_best > 16 || a.best_sims == nullptr || a.part_best == nullptr) return hipErrorInvalidValue;
     for (int q0 = 0; q0 < a.N; q0 += PR_Q) {   // part_best is the [16][M] similarity scratch

@@ -61,24 +61,28 @@ __global__ __launch_bounds__(256, 2) void k_vit_attention(const VitAttnArgs a) {
     const int row = row0 + 32 * i;
     lds_off[i] = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
   }
-  uint4 rk[2], rv[2];
-  auto load_tile = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = row0 + 32 * i;
-      rk[i] = *(const uint4*)(kb + (size_t)(kt * KV_TILE + row) * 64 + kc * 8);
-      rv[i] = *(const uint4*)(vb + (size_t)row * a.Tk + kt * KV_TILE + kc * 8);
-    }
-  };
-  auto store_tile = [&](int buf) {
-    char* sk = smem + buf * 2 * KV_TILE_BYTES;
-    char* sv = sk + KV_TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *(uint4*)(sk + lds_off[i]) = rk[i];
-      *(uint4*)(sv + lds_off[i]) = rv[i];
-    }
-  };
+  // staging registers: plain named values (arrays captured by lambdas end up in scratch)
+  uint4 rk0, rk1, rv0, rv1;
+  const T* k_src0 = kb + (size_t)row0 * 64 + kc * 8;
+  const T* k_src1 = kb + (size_t)(row0 + 32) * 64 + kc * 8;
+  const T* v_src0 = vb + (size_t)row0 * a.Tk + kc * 8;
+  const T* v_src1 = vb + (size_t)(row0 + 32) * a.Tk + kc * 8;
+#define PIO_LOAD_KV(kt)                                                 \
+  do {                                                                  \
+    rk0 = *(const uint4*)(k_src0 + (size_t)(kt) * KV_TILE * 64);        \
+    rk1 = *(const uint4*)(k_src1 + (size_t)(kt) * KV_TILE * 64);        \
+    rv0 = *(const uint4*)(v_src0 + (kt) * KV_TILE);                     \
+    rv1 = *(const uint4*)(v_src1 + (kt) * KV_TILE);                     \
+  } while (0)
+#define PIO_STORE_KV(buf)                                               \
+  do {                                                                  \
+    char* _sk = smem + (buf) * 2 * KV_TILE_BYTES;                       \
+    char* _sv = _sk + KV_TILE_BYTES;                                    \
+    *(uint4*)(_sk + lds_off[0]) = rk0;                                  \
+    *(uint4*)(_sk + lds_off[1]) = rk1;                                  \
+    *(uint4*)(_sv + lds_off[0]) = rv0;                                  \
+    *(uint4*)(_sv + lds_off[1]) = rv1;                                  \
+  } while (0)
 
   const int sw7 = (lane >> 1) & 7;
   const float sl2 = a.scale * 1.44269504088896340736f;  // softmax in the log2 domain
@@ -90,12 +94,13 @@ __global__ __launch_bounds__(256, 2) void k_vit_attention(const VitAttnArgs a) {
     for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
 
   const int nkt = (a.T + KV_TILE - 1) / KV_TILE;
-  load_tile(0);
-  store_tile(0);
+  PIO_LOAD_KV(0);
+  PIO_STORE_KV(0);
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1);
+    const int ktn = kt + 1 < nkt ? kt + 1 : kt;   // the last iteration reloads its own tile (never stored)
+    PIO_LOAD_KV(ktn);
     if (active) {
       const char* sk = smem + buf * 2 * KV_TILE_BYTES;
       const char* sv = sk + KV_TILE_BYTES;
@@ -160,9 +165,11 @@ __global__ __launch_bounds__(256, 2) void k_vit_attention(const VitAttnArgs a) {
           }
         }
     }
-    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    PIO_STORE_KV(buf ^ 1);   // harmless on the last iteration: that buffer is not read again
     __syncthreads();
   }
+#undef PIO_LOAD_KV
+#undef PIO_STORE_KV
 
   if (active) {
     const int q = q0 + r31;

@@ -20,21 +20,38 @@
 namespace pio {
 
 static constexpr int BM = 128, BN = 128, BK = 64;
+// diagnostic ablations (tools/microbench/gemm_ablate.hip); all 0 in the shipped library
+#ifndef PIO_ABL_NOGLOAD
+#define PIO_ABL_NOGLOAD 0
+#endif
+#ifndef PIO_ABL_NOEPI
+#define PIO_ABL_NOEPI 0
+#endif
+#ifndef PIO_ABL_NOMFMA
+#define PIO_ABL_NOMFMA 0
+#endif
+#ifndef PIO_ABL_NOLDSW
+#define PIO_ABL_NOLDSW 0
+#endif
 static constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// erf to 1.5e-7 absolute (Abramowitz-Stegun 7.1.26): one v_rcp + one v_exp + 7 FMAs instead of libdevice's
+// branchy erff; the result is rounded to fp16/bf16 anyway.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float r = 1.0f - poly * __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f)); }
 
-template <typename T, int EPI>
-__device__ __forceinline__ void epilogue_store(const GemmArgs& g, int m, int n, float v) {
-  if constexpr (EPI == EPI_PATCH_EMBED) {
-    const int b = m / g.n2, p = m - b * g.n2;
-    g.x[(size_t)(b * g.Tp + g.G + p) * g.D + n] = v + g.bias[n] + g.pos[(size_t)(1 + p) * g.D + n];
-  } else if constexpr (EPI == EPI_RESIDUAL) {
-    float* px = g.x + (size_t)m * g.N + n;
-    *px += g.ls[n] * (v + g.bias[n]);
-  } else if constexpr (EPI == EPI_GELU) {
-    ((T*)g.out16)[(size_t)m * g.N + n] = (T)gelu_erf(v + g.bias[n]);
-  }
+template <typename T>
+__device__ __forceinline__ void store_half4(T* dst, float a, float b, float c, float d) {
+  typedef T half4_t __attribute__((ext_vector_type(4)));
+  half4_t o;
+  o[0] = (T)a; o[1] = (T)b; o[2] = (T)c; o[3] = (T)d;
+  *(half4_t*)dst = o;
 }
 
 template <typename T, int EPI>
@@ -64,24 +81,6 @@ __global__ __launch_bounds__(256, 2) void k_vit_gemm(const GemmArgs g) {
     w_src[i] = (const T*)g.W + (size_t)(n0 + row) * g.K + kc * 8;
     lds_off[i] = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
   }
-  uint4 ra[4], rw[4];
-  auto load_tile = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = *(const uint4*)(a_src[i] + kt * BK);
-      rw[i] = *(const uint4*)(w_src[i] + kt * BK);
-    }
-  };
-  auto store_tile = [&](int buf) {
-    char* sa = smem + buf * 2 * TILE_BYTES;
-    char* sw = sa + TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *(uint4*)(sa + lds_off[i]) = ra[i];
-      *(uint4*)(sw + lds_off[i]) = rw[i];
-    }
-  };
-
   // ---- fragment read addresses ----
   const int sw7 = (lane >> 1) & 7;  // == ((row>>1)&7) for row = 32*x + (lane&31)
   int a_rd[2], w_rd[2];
@@ -99,70 +98,142 @@ __global__ __launch_bounds__(256, 2) void k_vit_gemm(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // staging registers are plain named values (no arrays captured by reference: hipcc keeps those in scratch)
+  uint4 ra0 = {}, ra1 = {}, ra2 = {}, ra3 = {}, rw0 = {}, rw1 = {}, rw2 = {}, rw3 = {};
+#define PIO_LOAD_TILE(kt)                                     \
+  do {                                                        \
+    const int _ko = (kt) * BK;                                \
+    if (PIO_ABL_NOGLOAD) break;                               \
+    ra0 = *(const uint4*)(a_src[0] + _ko);                    \
+    ra1 = *(const uint4*)(a_src[1] + _ko);                    \
+    ra2 = *(const uint4*)(a_src[2] + _ko);                    \
+    ra3 = *(const uint4*)(a_src[3] + _ko);                    \
+    rw0 = *(const uint4*)(w_src[0] + _ko);                    \
+    rw1 = *(const uint4*)(w_src[1] + _ko);                    \
+    rw2 = *(const uint4*)(w_src[2] + _ko);                    \
+    rw3 = *(const uint4*)(w_src[3] + _ko);                    \
+  } while (0)
+#define PIO_STORE_TILE(buf)                                   \
+  do {                                                        \
+    char* _sa = smem + (buf) * 2 * TILE_BYTES;                \
+    char* _sw = _sa + TILE_BYTES;                             \
+    if (PIO_ABL_NOLDSW) break;                                \
+    *(uint4*)(_sa + lds_off[0]) = ra0;                        \
+    *(uint4*)(_sa + lds_off[1]) = ra1;                        \
+    *(uint4*)(_sa + lds_off[2]) = ra2;                        \
+    *(uint4*)(_sa + lds_off[3]) = ra3;                        \
+    *(uint4*)(_sw + lds_off[0]) = rw0;                        \
+    *(uint4*)(_sw + lds_off[1]) = rw1;                        \
+    *(uint4*)(_sw + lds_off[2]) = rw2;                        \
+    *(uint4*)(_sw + lds_off[3]) = rw3;                        \
+  } while (0)
+#define PIO_COMPUTE_TILE(buf)                                                        \
+  do {                                                                               \
+    const char* _sa = smem + (buf) * 2 * TILE_BYTES;                                 \
+    const char* _sw = _sa + TILE_BYTES;                                              \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                  \
+      const int co = (((2 * s + h) ^ sw7) << 4);                                     \
+      const frag_t fa0 = *(const frag_t*)(_sa + a_rd[0] + co);                       \
+      const frag_t fa1 = *(const frag_t*)(_sa + a_rd[1] + co);                       \
+      const frag_t fw0 = *(const frag_t*)(_sw + w_rd[0] + co);                       \
+      const frag_t fw1 = *(const frag_t*)(_sw + w_rd[1] + co);                       \
+      if (PIO_ABL_NOMFMA) {                                                          \
+        asm volatile("" ::"v"(fa0), "v"(fa1), "v"(fw0), "v"(fw1));                   \
+        continue;                                                                    \
+      }                                                                              \
+      acc[0][0] = mfma32(fa0, fw0, acc[0][0]);                                       \
+      acc[0][1] = mfma32(fa0, fw1, acc[0][1]);                                       \
+      acc[1][0] = mfma32(fa1, fw0, acc[1][0]);                                       \
+      acc[1][1] = mfma32(fa1, fw1, acc[1][1]);                                       \
+    }                                                                                \
+  } while (0)
+
   const int nk = g.K / BK;
-  load_tile(0);
-  store_tile(0);
+  PIO_LOAD_TILE(0);
+  PIO_STORE_TILE(0);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = 0; kt < nk - 1; ++kt) {     // steady state: prefetch kt+1 while computing kt
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
-    const char* sa = smem + buf * 2 * TILE_BYTES;
-    const char* sw = sa + TILE_BYTES;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int co = (((2 * s + h) ^ sw7) << 4);
-      frag_t fa[2], fw[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = *(const frag_t*)(sa + a_rd[i] + co);
-        fw[i] = *(const frag_t*)(sw + w_rd[i] + co);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i], fw[j], acc[i][j]);
-    }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+    PIO_LOAD_TILE(kt + 1);
+    PIO_COMPUTE_TILE(buf);
+    PIO_STORE_TILE(buf ^ 1);
     __syncthreads();
   }
+  PIO_COMPUTE_TILE((nk - 1) & 1);
+#undef PIO_LOAD_TILE
+#undef PIO_STORE_TILE
+#undef PIO_COMPUTE_TILE
 
-  // ---- epilogue ----
-  if constexpr (EPI == EPI_QKV) {
-    T* qb = (T*)g.q; T* kb = (T*)g.k; T* vb = (T*)g.vT;
+  // ---- epilogue: accumulators -> LDS [128][128] fp32 -> row-major 16-B-per-lane global accesses ----
+  if (PIO_ABL_NOEPI) {
+    if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] == 12345.678f) g.x[tid] = 1.f;   // keep acc live
+    return;
+  }
+  __syncthreads();                       // every wave is done reading the operand tiles
+  float* ct = (float*)smem;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + acc_row32(r, lane);
-        if (m >= g.M) continue;
-        const int b = m / g.Tp, t = m - b * g.Tp;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int n = n0 + wn * 64 + j * 32 + r31;
-          const float v = acc[i][j][r] + g.bias[n];
-          const int which = n / g.D, hd = n - which * g.D;
-          const int head = hd >> 6, d = hd & 63;
-          const size_t bh = (size_t)b * g.H + head;
-          if (which == 0) qb[(bh * g.Tk + t) * 64 + d] = (T)v;
-          else if (which == 1) kb[(bh * g.Tk + t) * 64 + d] = (T)v;
-          else vb[(bh * 64 + d) * g.Tk + t] = (T)v;
-          if (g.qkv_last != nullptr && t < g.T) g.qkv_last[((size_t)b * g.T + t) * g.N + n] = v;
-        }
+      for (int r = 0; r < 16; ++r)
+        ct[(wm * 64 + i * 32 + acc_row32(r, lane)) * BN + wn * 64 + j * 32 + r31] = acc[i][j][r];
+  __syncthreads();
+
+  if (EPI == EPI_QKV && n0 >= 2 * g.D) {
+    // V block: stored transposed ([b][h][d][t]); each thread takes one column and 4 consecutive tokens
+    // (Tp % 8 == 0 and m0 % 128 == 0, so the 4 tokens belong to one image and the 8-B store is aligned)
+    const int col = tid & 127, rg = tid >> 7;
+    const int n = n0 + col, hd = n - 2 * g.D, head = hd >> 6, d = hd & 63;
+    const float bn = g.bias[n];
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int r4 = (rg + 2 * i) * 4, m = m0 + r4;
+      if (m >= g.M) continue;
+      const int b = m / g.Tp, t = m - b * g.Tp;
+      const float v0 = ct[(r4 + 0) * BN + col] + bn, v1 = ct[(r4 + 1) * BN + col] + bn;
+      const float v2 = ct[(r4 + 2) * BN + col] + bn, v3 = ct[(r4 + 3) * BN + col] + bn;
+      store_half4<T>((T*)g.vT + ((size_t)(b * g.H + head) * 64 + d) * g.Tk + t, v0, v1, v2, v3);
+      if (g.qkv_last != nullptr) {
+        float* ql = g.qkv_last + ((size_t)b * g.T + t) * g.N + n;
+        if (t + 0 < g.T) ql[0] = v0;
+        if (t + 1 < g.T) ql[(size_t)g.N] = v1;
+        if (t + 2 < g.T) ql[(size_t)2 * g.N] = v2;
+        if (t + 3 < g.T) ql[(size_t)3 * g.N] = v3;
       }
     }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + acc_row32(r, lane);
-        if (m >= g.M) continue;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int n = n0 + wn * 64 + j * 32 + r31;
-          epilogue_store<T, EPI>(g, m, n, acc[i][j][r]);
-        }
-      }
+    return;
+  }
+  const int c4 = (tid & 31) * 4, rbase = tid >> 5;
+  const int n = n0 + c4;
+  const float4 b4 = *(const float4*)(g.bias + n);
+  float4 l4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (EPI == EPI_RESIDUAL) l4 = *(const float4*)(g.ls + n);
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int row = rbase + 8 * i, m = m0 + row;
+    if (m >= g.M) continue;
+    float4 v = *(const float4*)(ct + row * BN + c4);
+    v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+    if constexpr (EPI == EPI_PATCH_EMBED) {
+      const int b = m / g.n2, p = m - b * g.n2;
+      const float4 ps = *(const float4*)(g.pos + (size_t)(1 + p) * g.D + n);
+      *(float4*)(g.x + (size_t)(b * g.Tp + g.G + p) * g.D + n) = make_float4(v.x + ps.x, v.y + ps.y, v.z + ps.z, v.w + ps.w);
+    } else if constexpr (EPI == EPI_RESIDUAL) {
+      float4* px = (float4*)(g.x + (size_t)m * g.N + n);
+      float4 xo = *px;
+      xo.x += l4.x * v.x; xo.y += l4.y * v.y; xo.z += l4.z * v.z; xo.w += l4.w * v.w;
+      *px = xo;
+    } else if constexpr (EPI == EPI_GELU) {
+      store_half4<T>((T*)g.out16 + (size_t)m * g.N + n, gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+    } else {  // EPI_QKV, q or k block (block-uniform: D % 128 == 0)
+      const int which = n0 >= g.D ? 1 : 0;
+      const int hd = n - which * g.D, head = hd >> 6, d = hd & 63;
+      const int b = m / g.Tp, t = m - b * g.Tp;
+      T* dst = (which == 0 ? (T*)g.q : (T*)g.k) + ((size_t)(b * g.H + head) * g.Tk + t) * 64 + d;
+      store_half4<T>(dst, v.x, v.y, v.z, v.w);
+      if (g.qkv_last != nullptr && t < g.T) *(float4*)(g.qkv_last + ((size_t)b * g.T + t) * g.N + n) = v;
+    }
   }
 }
 
