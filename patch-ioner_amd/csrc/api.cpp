@@ -91,11 +91,12 @@ struct pio_context {
   // read-out workspaces
   float* head_logits = nullptr; float* head_sm = nullptr; int32_t* head_img = nullptr;
   // decoder weights
-  float *clip_w = nullptr, *clip_b = nullptr, *wte = nullptr, *wpe = nullptr, *lnf_w = nullptr, *lnf_b = nullptr;
+  float *clip_w = nullptr, *clip_b = nullptr, *wte = nullptr, *wpe = nullptr, *head_w = nullptr, *head_c = nullptr,
+        *head_d = nullptr;
   std::vector<DecLayerW> dl;
   // decoder workspaces
-  float *dx = nullptr, *dy = nullptr, *dqkv = nullptr, *datt = nullptr, *dhid = nullptr, *kcache = nullptr,
-        *vcache = nullptr, *logits = nullptr, *dpart = nullptr, *prefix_buf = nullptr, *logprob_buf = nullptr;
+  float *dx = nullptr, *dqkv = nullptr, *datt = nullptr, *dhid = nullptr, *kcache = nullptr,
+        *vcache = nullptr, *logits = nullptr, *prefix_buf = nullptr, *logprob_buf = nullptr;
   int32_t* ids_buf = nullptr;
   std::map<GraphKey, hipGraphExec_t> graphs;
   hipStream_t capture_stream = nullptr;
@@ -255,54 +256,89 @@ int finalize_vit(pio_context* c) {
   return PIO_OK;
 }
 
+// W [in][out] (Conv1D) or [out][in] (Linear) -> LayerNorm-folded [out][in] weight plus the two epilogue
+// vectors of decoder.hip:  w'_jk = W_jk ln_w_k,  c_j = sum_k w'_jk,  d_j = sum_k ln_b_k W_jk + b_j.
+int upload_ln_folded(pio_context* c, const float* W, bool in_major, int64_t in, int64_t out, const float* lnw,
+                     const float* lnb, const float* bias, float** dw, float** dc, float** dd) {
+  std::vector<float> w((size_t)in * out), cv(out), dv(out);
+  for (int64_t j = 0; j < out; ++j) {
+    double cs = 0.0, ds = bias ? (double)bias[j] : 0.0;
+    for (int64_t k = 0; k < in; ++k) {
+      const float wjk = in_major ? W[(size_t)k * out + j] : W[(size_t)j * in + k];
+      const float f = wjk * lnw[k];
+      w[(size_t)j * in + k] = f;
+      cs += (double)f;
+      ds += (double)lnb[k] * (double)wjk;
+    }
+    cv[j] = (float)cs;
+    dv[j] = (float)ds;
+  }
+  int rc;
+  if ((rc = upload_f32(c, w.data(), w.size(), dw))) return rc;
+  if ((rc = upload_f32(c, cv.data(), cv.size(), dc))) return rc;
+  return upload_f32(c, dv.data(), dv.size(), dd);
+}
+
 int finalize_decoder(pio_context* c) {
   const int E = c->cfg.dec_embd, V = c->cfg.dec_vocab, P = c->cfg.dec_positions, L = c->cfg.dec_layers;
   const int PS = c->cfg.prefix_size;
-  const HostTensor* t;
+  if (E != 768) return fail(PIO_ERR_SHAPE, "decoder kernels are built for n_embd = 768 (the DeCap GPT-2 config)");
+  const HostTensor *t, *tw, *tb, *tl, *tlb;
   int rc;
   if ((rc = need(c, "clip_project.model.0.weight", {E, PS}, &t))) return rc;
   if ((rc = upload_f32(c, t->data.data(), (size_t)E * PS, &c->clip_w))) return rc;
   if ((rc = need(c, "clip_project.model.0.bias", {E}, &t))) return rc;
   if ((rc = upload_f32(c, t->data.data(), E, &c->clip_b))) return rc;
-  if ((rc = need(c, "decoder.transformer.wte.weight", {V, E}, &t))) return rc;
-  if ((rc = upload_f32(c, t->data.data(), (size_t)V * E, &c->wte))) return rc;
+  if ((rc = need(c, "decoder.transformer.wte.weight", {V, E}, &tw))) return rc;
+  if ((rc = upload_f32(c, tw->data.data(), (size_t)V * E, &c->wte))) return rc;
   if ((rc = need(c, "decoder.transformer.wpe.weight", {P, E}, &t))) return rc;
   if ((rc = upload_f32(c, t->data.data(), (size_t)P * E, &c->wpe))) return rc;
-  if ((rc = need(c, "decoder.transformer.ln_f.weight", {E}, &t))) return rc;
-  if ((rc = upload_f32(c, t->data.data(), E, &c->lnf_w))) return rc;
-  if ((rc = need(c, "decoder.transformer.ln_f.bias", {E}, &t))) return rc;
-  if ((rc = upload_f32(c, t->data.data(), E, &c->lnf_b))) return rc;
+  // tied LM head with ln_f folded in (a second, scaled copy of wte)
+  if ((rc = need(c, "decoder.transformer.ln_f.weight", {E}, &tl))) return rc;
+  if ((rc = need(c, "decoder.transformer.ln_f.bias", {E}, &tlb))) return rc;
+  if ((rc = upload_ln_folded(c, tw->data.data(), false, E, V, tl->data.data(), tlb->data.data(), nullptr, &c->head_w,
+                             &c->head_c, &c->head_d))) return rc;
   c->dl.resize(L);
   for (int l = 0; l < L; ++l) {
     DecLayerW& w = c->dl[l];
     const std::string pre = "decoder.transformer.h." + std::to_string(l) + ".";
-    struct F { const char* key; int64_t n; const float** dst; };
-    F fs[] = {{"ln_1.weight", E, &w.ln1_w}, {"ln_1.bias", E, &w.ln1_b}, {"attn.c_attn.bias", 3 * E, &w.attn_b},
-              {"attn.c_proj.bias", E, &w.proj_b}, {"ln_2.weight", E, &w.ln2_w}, {"ln_2.bias", E, &w.ln2_b},
-              {"mlp.c_fc.bias", 4 * E, &w.fc_b}, {"mlp.c_proj.bias", E, &w.fc2_b}};
-    for (auto& f : fs) {
-      if ((rc = need(c, pre + f.key, {f.n}, &t))) return rc;
-      float* d;
-      if ((rc = upload_f32(c, t->data.data(), f.n, &d))) return rc;
-      *f.dst = d;
-    }
-    struct Wm { const char* key; int64_t in, out; const float** dst; };
-    Wm ws[] = {{"attn.c_attn.weight", E, 3 * E, &w.attn_w}, {"attn.c_proj.weight", E, E, &w.proj_w},
-               {"mlp.c_fc.weight", E, 4 * E, &w.fc_w}, {"mlp.c_proj.weight", 4 * E, E, &w.fc2_w}};
-    for (auto& m : ws) {
-      if ((rc = need(c, pre + m.key, {m.in, m.out}, &t))) return rc;
-      float* d;
-      if ((rc = upload_transposed(c, t->data.data(), m.in, m.out, &d))) return rc;
-      *m.dst = d;
-    }
+    float *dw, *dc, *dd;
+    // ln_1 -> attn.c_attn
+    if ((rc = need(c, pre + "attn.c_attn.weight", {E, 3 * E}, &tw))) return rc;
+    if ((rc = need(c, pre + "attn.c_attn.bias", {3 * E}, &tb))) return rc;
+    if ((rc = need(c, pre + "ln_1.weight", {E}, &tl))) return rc;
+    if ((rc = need(c, pre + "ln_1.bias", {E}, &tlb))) return rc;
+    if ((rc = upload_ln_folded(c, tw->data.data(), true, E, 3 * E, tl->data.data(), tlb->data.data(), tb->data.data(),
+                               &dw, &dc, &dd))) return rc;
+    w.attn_w = dw; w.attn_c = dc; w.attn_d = dd;
+    // ln_2 -> mlp.c_fc
+    if ((rc = need(c, pre + "mlp.c_fc.weight", {E, 4 * E}, &tw))) return rc;
+    if ((rc = need(c, pre + "mlp.c_fc.bias", {4 * E}, &tb))) return rc;
+    if ((rc = need(c, pre + "ln_2.weight", {E}, &tl))) return rc;
+    if ((rc = need(c, pre + "ln_2.bias", {E}, &tlb))) return rc;
+    if ((rc = upload_ln_folded(c, tw->data.data(), true, E, 4 * E, tl->data.data(), tlb->data.data(), tb->data.data(),
+                               &dw, &dc, &dd))) return rc;
+    w.fc_w = dw; w.fc_c = dc; w.fc_d = dd;
+    // residual-branch outputs: plain [out][in] transposes
+    if ((rc = need(c, pre + "attn.c_proj.weight", {E, E}, &tw))) return rc;
+    if ((rc = upload_transposed(c, tw->data.data(), E, E, &dw))) return rc;
+    w.proj_w = dw;
+    if ((rc = need(c, pre + "attn.c_proj.bias", {E}, &tb))) return rc;
+    if ((rc = upload_f32(c, tb->data.data(), E, &dw))) return rc;
+    w.proj_b = dw;
+    if ((rc = need(c, pre + "mlp.c_proj.weight", {4 * E, E}, &tw))) return rc;
+    if ((rc = upload_transposed(c, tw->data.data(), 4 * E, E, &dw))) return rc;
+    w.fc2_w = dw;
+    if ((rc = need(c, pre + "mlp.c_proj.bias", {E}, &tb))) return rc;
+    if ((rc = upload_f32(c, tb->data.data(), E, &dw))) return rc;
+    w.fc2_b = dw;
   }
+  HIP_OK(decoder_init());
   const size_t N = c->cfg.max_prefixes, S = c->cfg.max_steps;
   if ((rc = c->dmalloc(&c->dx, N * E, true))) return rc;
-  if ((rc = c->dmalloc(&c->dy, N * E, true))) return rc;
   if ((rc = c->dmalloc(&c->dqkv, N * 3 * E, true))) return rc;
   if ((rc = c->dmalloc(&c->datt, N * E, true))) return rc;
   if ((rc = c->dmalloc(&c->dhid, N * 4 * E, true))) return rc;
-  if ((rc = c->dmalloc(&c->dpart, 4 * N * E, true))) return rc;
   if ((rc = c->dmalloc(&c->kcache, (size_t)L * N * S * E, true))) return rc;
   if ((rc = c->dmalloc(&c->vcache, (size_t)L * N * S * E, true))) return rc;
   if ((rc = c->dmalloc(&c->logits, N * V, true))) return rc;
@@ -339,8 +375,8 @@ int pio_create(const pio_config* cfg, pio_handle* out) {
     return fail(PIO_ERR_INVALID_ARG, "pio_create: backbone head_dim must be 64 (embed_dim = 64 * num_heads)");
   if (cfg->crop_dim % cfg->patch_size != 0)
     return fail(PIO_ERR_INVALID_ARG, "pio_create: crop_dim must be a multiple of patch_size");
-  if (cfg->max_batch < 1 || cfg->max_prefixes < 1 || cfg->max_prefixes > 128 || cfg->max_steps < 1 || cfg->max_steps > 64)
-    return fail(PIO_ERR_INVALID_ARG, "pio_create: capacities out of range (prefixes <= 128, steps <= 64)");
+  if (cfg->max_batch < 1 || cfg->max_prefixes < 1 || cfg->max_prefixes > 64 || cfg->max_steps < 1 || cfg->max_steps > 64)
+    return fail(PIO_ERR_INVALID_ARG, "pio_create: capacities out of range (prefixes <= 64, steps <= 64)");
   if (cfg->readout_heads != 16) return fail(PIO_ERR_INVALID_ARG, "pio_create: readout_heads must be 16");
   int ndev = 0;
   HIP_OK(hipGetDeviceCount(&ndev));
@@ -632,8 +668,8 @@ int pio_decode_greedy(pio_handle c, const float* prefix, int32_t N, int32_t step
   DecoderArgs a;
   a.N = N; a.steps = steps; a.E = E; a.heads = c->cfg.dec_heads; a.layers = c->cfg.dec_layers; a.vocab = c->cfg.dec_vocab;
   a.prefix_size = PS; a.eps = c->cfg.dec_ln_eps; a.prefix = c->prefix_buf; a.clip_w = c->clip_w; a.clip_b = c->clip_b;
-  a.wte = c->wte; a.wpe = c->wpe; a.lnf_w = c->lnf_w; a.lnf_b = c->lnf_b; a.layer = c->dl.data();
-  a.x = c->dx; a.y = c->dy; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.part = c->dpart; a.kcache = c->kcache; a.vcache = c->vcache;
+  a.wte = c->wte; a.wpe = c->wpe; a.head_w = c->head_w; a.head_c = c->head_c; a.head_d = c->head_d; a.layer = c->dl.data();
+  a.x = c->dx; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.kcache = c->kcache; a.vcache = c->vcache;
   a.max_steps = c->cfg.max_steps; a.logits = c->logits; a.ids = c->ids_buf; a.logprob = logprob ? c->logprob_buf : nullptr;
   HIP_OK(hipMemcpyAsync(c->prefix_buf, prefix, (size_t)N * PS * 4, hipMemcpyDeviceToDevice, s));
   // algorithmic work of a KV-cached decode: per token 4 layers x 12 E^2 MACs + the tied LM head;

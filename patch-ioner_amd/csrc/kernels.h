@@ -95,23 +95,24 @@ hipError_t launch_revert(const float* x, const float* b, const float* A_pinv, in
 // ---------------------------------------------------------------------------------------------
 // DeCap decoder (fp32, KV-cached greedy)
 // ---------------------------------------------------------------------------------------------
+// LayerNorm-folded linear layers (decoder.hip header): w = W * ln_w per input channel, c_j = sum_k w_jk,
+// d_j = sum_k ln_b_k W_jk + b_j.
 struct DecLayerW {
-  const float *ln1_w, *ln1_b, *attn_w /*[3E][E]*/, *attn_b, *proj_w /*[E][E]*/, *proj_b;
-  const float *ln2_w, *ln2_b, *fc_w /*[4E][E]*/, *fc_b, *fc2_w /*[E][4E]*/, *fc2_b;
+  const float *attn_w /*[3E][E] folded*/, *attn_c, *attn_d, *proj_w /*[E][E]*/, *proj_b;
+  const float *fc_w /*[4E][E] folded*/, *fc_c, *fc_d, *fc2_w /*[E][4E]*/, *fc2_b;
 };
 struct DecoderArgs {
   int N, steps, E, heads, layers, vocab, prefix_size;
   float eps;
   const float* prefix;        // [N][prefix_size]
-  const float *clip_w /*[E][prefix]*/, *clip_b, *wte /*[V][E]*/, *wpe /*[P][E]*/, *lnf_w, *lnf_b;
+  const float *clip_w /*[E][prefix]*/, *clip_b, *wte /*[V][E]*/, *wpe /*[P][E]*/;
+  const float *head_w /*[V][E] = wte * ln_f.weight*/, *head_c, *head_d;
   const DecLayerW* layer;     // host array [layers]
   // workspaces
   float* x;      // [N][E] residual
-  float* y;      // [N][E] LayerNorm output
   float* qkv;    // [N][3E]
   float* att;    // [N][E]
   float* hid;    // [N][4E]
-  float* part;   // [4][N][E] split-K partial sums of the residual branches
   float* kcache; // [layers][N][max_steps][E]
   float* vcache;
   int max_steps;
@@ -120,5 +121,6 @@ struct DecoderArgs {
   float* logprob;    // [N][steps] or null
 };
 hipError_t launch_decode_greedy(const DecoderArgs& a, hipStream_t s);
+hipError_t decoder_init();   // one-time function attributes (call outside stream capture)
 
 }  // namespace pio
