@@ -26,6 +26,17 @@
 
 namespace pio {
 
+// diagnostic ablations (tools/microbench/dec_bench.hip); all off in the shipped library
+#ifndef PIO_DABL_NOX
+#define PIO_DABL_NOX 0
+#endif
+#ifndef PIO_DABL_NOMFMA
+#define PIO_DABL_NOMFMA 0
+#endif
+#ifndef PIO_LMHEAD_CG
+#define PIO_LMHEAD_CG 1
+#endif
+
 enum DecEpi { DE_STORE = 0, DE_RESID = 1, DE_GELU = 2, DE_EMBED = 3, DE_ARGMAX = 4 };
 
 __device__ __forceinline__ f32x4 mfma16f(float a, float b, f32x4 c) {
@@ -73,7 +84,7 @@ __global__ __launch_bounds__(64 * NW) void k_dec_gemm(const float* __restrict__ 
     const float* xp = X + (size_t)n * K + k0;
     float4 x4[CPW];
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) x4[c] = *(const float4*)(xp + 16 * c);   // activations: L2-resident
+    for (int c = 0; c < CPW; ++c) x4[c] = PIO_DABL_NOX ? make_float4(0.5f, 0.25f, 1.f, 2.f) : *(const float4*)(xp + 16 * c);   // activations: L2-resident
     __builtin_amdgcn_sched_barrier(0);
     f32x4 a[CG];
 #pragma unroll
@@ -83,6 +94,7 @@ __global__ __launch_bounds__(64 * NW) void k_dec_gemm(const float* __restrict__ 
     for (int c = 0; c < CPW; ++c) {
 #pragma unroll
       for (int q = 0; q < CG; ++q) {
+        if (PIO_DABL_NOMFMA) { a[q][0] += x4[c].x * w4[q][c].x + x4[c].y * w4[q][c].y + x4[c].z * w4[q][c].z + x4[c].w * w4[q][c].w; continue; }
         a[q] = mfma16f(x4[c].x, w4[q][c].x, a[q]);
         a[q] = mfma16f(x4[c].y, w4[q][c].y, a[q]);
         a[q] = mfma16f(x4[c].z, w4[q][c].z, a[q]);
@@ -305,7 +317,7 @@ template <int EPI, int LN>
 static hipError_t dec_gemm(const float* W, const float* X, int N, int Nout, int K, const float* bias, float* out,
                            const float* extra, const float* cvec, float eps, hipStream_t s) {
   if (N < 1 || N > 128) return hipErrorInvalidValue;
-  constexpr int CG = EPI == DE_ARGMAX ? 2 : 1;   // LM head: 32 columns per workgroup halve the re-reads of x
+  constexpr int CG = EPI == DE_ARGMAX ? PIO_LMHEAD_CG : 1;   // LM head: 32 columns per workgroup halve the re-reads of x
   if (K == 768) return dec_gemm_rg<12, 4, EPI, LN, CG>(W, X, N, Nout, K, bias, out, extra, cvec, eps, s);
   if (K == 512) return dec_gemm_rg<8, 4, EPI, LN, CG>(W, X, N, Nout, K, bias, out, extra, cvec, eps, s);
   if (K == 3072) return dec_gemm_rg<12, 16, EPI, LN, CG>(W, X, N, Nout, K, bias, out, extra, cvec, eps, s);
@@ -320,12 +332,21 @@ hipError_t decoder_init() {
 
 #define PIO_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
 
+// LM head -> greedy partials: one (max, arg-max, sum-exp) per prefix and 16-column group.
+// (A persistent variant that keeps x in registers and walks 5-7 column groups per workgroup measured
+//  50 us against 41 us for this one at 16 prefixes: fewer bytes in flight per CU and a serial per-group
+//  epilogue; dropped.)
+hipError_t launch_lmhead(const float* W, const float* X, int N, int V, int E, const float* dvec, const float* cvec,
+                         float eps, float* part, int* nblk, hipStream_t s) {
+  *nblk = ceil_div(V, 16);
+  return dec_gemm<DE_ARGMAX, 1>(W, X, N, V, E, dvec, part, nullptr, cvec, eps, s);
+}
+
 hipError_t launch_decode_greedy(const DecoderArgs& a, hipStream_t s) {
   const int N = a.N, E = a.E;
   if (a.steps > a.max_steps || a.steps > 64 || E != 768 || (E / a.heads) % 32 != 0 || (E / a.heads) > 256 || N > 64)
     return hipErrorInvalidValue;
-  const int nblk = ceil_div(a.vocab, 32) * 2;   // (max, arg-max, sum-exp) partials: one per 16 LM-head columns
-  if (nblk > 4096) return hipErrorInvalidValue;
+  if (ceil_div(a.vocab, 16) > 4096) return hipErrorInvalidValue;
   // step 0 input: clip_project(prefix) + wpe[0]   (decap.py:124; GPT-2 adds wpe to inputs_embeds)
   PIO_TRY((dec_gemm<DE_EMBED, 0>(a.clip_w, a.prefix, N, E, a.prefix_size, a.clip_b, a.x, a.wpe, nullptr, 0.f, s)));
   for (int step = 0; step < a.steps; ++step) {
@@ -340,7 +361,8 @@ hipError_t launch_decode_greedy(const DecoderArgs& a, hipStream_t s) {
       PIO_TRY((dec_gemm<DE_GELU, 1>(w.fc_w, a.x, N, 4 * E, E, w.fc_d, a.hid, nullptr, w.fc_c, a.eps, s)));
       PIO_TRY((dec_gemm<DE_RESID, 0>(w.fc2_w, a.hid, N, E, 4 * E, w.fc2_b, a.x, nullptr, nullptr, 0.f, s)));
     }
-    PIO_TRY((dec_gemm<DE_ARGMAX, 1>(a.head_w, a.x, N, a.vocab, E, a.head_d, a.logits, nullptr, a.head_c, a.eps, s)));
+    int nblk = 0;
+    PIO_TRY(launch_lmhead(a.head_w, a.x, N, a.vocab, E, a.head_d, a.head_c, a.eps, a.logits, &nblk, s));
     hipLaunchKernelGGL(k_dec_select, dim3(N), dim3(256), 0, s, a.logits, nblk, N, E, step, a.steps, a.wte, a.wpe,
                        a.ids, a.logprob, a.x);
   }

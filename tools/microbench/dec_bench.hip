@@ -1,0 +1,64 @@
+// Stand-alone timing of the decoder kernels (diagnostic, never shipped):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I patch-ioner_amd/csrc tools/microbench/dec_bench.hip -o dec_bench
+// Each kernel is launched in a dependent chain of ITER launches on one stream (like the decode graph) and the
+// per-launch time is the elapsed time / ITER.
+#include "../../patch-ioner_amd/csrc/decoder.hip"
+#include <cstdio>
+#include <cstring>
+#include <vector>
+using namespace pio;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <typename F>
+static float time_chain(F f, int iter = 200) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 10; ++i) f();
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < iter; ++i) f();
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e3f / iter;
+}
+
+int main(int argc, char** argv) {
+  const int N = argc > 1 ? atoi(argv[1]) : 16;
+  const int E = 768, V = 50257, S = 32, heads = 4;
+  float *w_qkv, *w_proj, *w_fc, *w_fc2, *w_head, *x, *qkv, *att, *hid, *part, *bias, *cvec, *kc, *vc, *wte, *wpe;
+  int32_t* ids; float* lp;
+  CK(hipMalloc(&w_qkv, (size_t)3 * E * E * 4)); CK(hipMalloc(&w_proj, (size_t)E * E * 4));
+  CK(hipMalloc(&w_fc, (size_t)4 * E * E * 4)); CK(hipMalloc(&w_fc2, (size_t)4 * E * E * 4));
+  CK(hipMalloc(&w_head, (size_t)V * E * 4)); CK(hipMalloc(&wte, (size_t)V * E * 4)); CK(hipMalloc(&wpe, (size_t)1024 * E * 4));
+  CK(hipMalloc(&x, (size_t)N * E * 4)); CK(hipMalloc(&qkv, (size_t)N * 3 * E * 4)); CK(hipMalloc(&att, (size_t)N * E * 4));
+  CK(hipMalloc(&hid, (size_t)N * 4 * E * 4)); CK(hipMalloc(&part, (size_t)4096 * N * 4 * 4));
+  CK(hipMalloc(&bias, (size_t)V * 4)); CK(hipMalloc(&cvec, (size_t)V * 4));
+  CK(hipMalloc(&kc, (size_t)N * S * E * 4)); CK(hipMalloc(&vc, (size_t)N * S * E * 4));
+  CK(hipMalloc(&ids, (size_t)N * S * 4)); CK(hipMalloc(&lp, (size_t)N * S * 4));
+  std::vector<float> h((size_t)V * E);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = ((int)((i * 2654435761u) >> 20) % 2001 - 1000) * 2e-5f;
+  CK(hipMemcpy(w_head, h.data(), h.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(wte, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(w_qkv, h.data(), (size_t)3 * E * E * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(w_proj, h.data(), (size_t)E * E * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(w_fc, h.data(), (size_t)4 * E * E * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(w_fc2, h.data(), (size_t)4 * E * E * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(wpe, h.data(), (size_t)1024 * E * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(x, h.data(), (size_t)N * E * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(hid, h.data(), (size_t)N * 4 * E * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(att, h.data(), (size_t)N * E * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(bias, h.data(), (size_t)V * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(cvec, h.data(), (size_t)V * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(kc, 0, (size_t)N * S * E * 4)); CK(hipMemset(vc, 0, (size_t)N * S * E * 4)); CK(hipMemset(qkv, 0, (size_t)N * 3 * E * 4));
+  CK(decoder_init());
+  hipStream_t s = 0;
+  int nblk = 0;
+  printf("N=%d\n", N);
+  printf("qkv  (LN, store)   %7.2f us\n", time_chain([&] { dec_gemm<DE_STORE, 1>(w_qkv, x, N, 3 * E, E, bias, qkv, nullptr, cvec, 1e-5f, s); }));
+  printf("attention pos=15   %7.2f us\n", time_chain([&] { hipLaunchKernelGGL(k_dec_attention, dim3(N * heads), dim3(256), 0, s, qkv, kc, vc, E, heads, 15, S, att); }));
+  printf("attention pos=29   %7.2f us\n", time_chain([&] { hipLaunchKernelGGL(k_dec_attention, dim3(N * heads), dim3(256), 0, s, qkv, kc, vc, E, heads, 29, S, att); }));
+  printf("proj (resid)       %7.2f us\n", time_chain([&] { dec_gemm<DE_RESID, 0>(w_proj, att, N, E, E, bias, x, nullptr, nullptr, 0.f, s); }));
+  printf("fc   (LN, gelu)    %7.2f us\n", time_chain([&] { dec_gemm<DE_GELU, 1>(w_fc, x, N, 4 * E, E, bias, hid, nullptr, cvec, 1e-5f, s); }));
+  printf("fc2  (resid)       %7.2f us\n", time_chain([&] { dec_gemm<DE_RESID, 0>(w_fc2, hid, N, E, 4 * E, bias, x, nullptr, nullptr, 0.f, s); }));
+  printf("lm head (argmax)   %7.2f us\n", time_chain([&] { launch_lmhead(w_head, x, N, V, E, bias, cvec, 1e-5f, part, &nblk, s); }, 50));
+  printf("lm head generic    %7.2f us\n", time_chain([&] { dec_gemm<DE_ARGMAX, 1>(w_head, x, N, V, E, bias, part, nullptr, cvec, 1e-5f, s); }, 50));
+  printf("select             %7.2f us\n", time_chain([&] { hipLaunchKernelGGL(k_dec_select, dim3(N), dim3(256), 0, s, part, nblk, N, E, 3, S, wte, wpe, ids, lp, x); }));
+  CK(hipDeviceSynchronize());
+  return 0;
+}
