@@ -96,8 +96,9 @@ struct pio_context {
   std::vector<DecLayerW> dl;
   // decoder workspaces
   float *dx = nullptr, *dqkv = nullptr, *datt = nullptr, *dhid = nullptr, *kcache = nullptr,
-        *vcache = nullptr, *logits = nullptr, *prefix_buf = nullptr, *logprob_buf = nullptr;
+        *vcache = nullptr, *logits = nullptr, *splitk_ws = nullptr, *prefix_buf = nullptr, *logprob_buf = nullptr;
   int32_t* ids_buf = nullptr;
+  unsigned* splitk_cnt = nullptr;
   std::map<GraphKey, hipGraphExec_t> graphs;
   hipStream_t capture_stream = nullptr;
   bool use_graph = true;
@@ -339,6 +340,8 @@ int finalize_decoder(pio_context* c) {
   if ((rc = c->dmalloc(&c->dqkv, N * 3 * E, true))) return rc;
   if ((rc = c->dmalloc(&c->datt, N * E, true))) return rc;
   if ((rc = c->dmalloc(&c->dhid, N * 4 * E, true))) return rc;
+  if ((rc = c->dmalloc(&c->splitk_ws, (size_t)64 * 4 * 4 * 256, true))) return rc;
+  if ((rc = c->dmalloc(&c->splitk_cnt, 64, true))) return rc;
   if ((rc = c->dmalloc(&c->kcache, (size_t)L * N * S * E, true))) return rc;
   if ((rc = c->dmalloc(&c->vcache, (size_t)L * N * S * E, true))) return rc;
   if ((rc = c->dmalloc(&c->logits, N * V, true))) return rc;
@@ -669,9 +672,10 @@ int pio_decode_greedy(pio_handle c, const float* prefix, int32_t N, int32_t step
   a.N = N; a.steps = steps; a.E = E; a.heads = c->cfg.dec_heads; a.layers = c->cfg.dec_layers; a.vocab = c->cfg.dec_vocab;
   a.prefix_size = PS; a.eps = c->cfg.dec_ln_eps; a.prefix = c->prefix_buf; a.clip_w = c->clip_w; a.clip_b = c->clip_b;
   a.wte = c->wte; a.wpe = c->wpe; a.head_w = c->head_w; a.head_c = c->head_c; a.head_d = c->head_d; a.layer = c->dl.data();
-  a.x = c->dx; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.kcache = c->kcache; a.vcache = c->vcache;
+  a.x = c->dx; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.splitk_ws = c->splitk_ws; a.splitk_cnt = c->splitk_cnt; a.kcache = c->kcache; a.vcache = c->vcache;
   a.max_steps = c->cfg.max_steps; a.logits = c->logits; a.ids = c->ids_buf; a.logprob = logprob ? c->logprob_buf : nullptr;
   HIP_OK(hipMemcpyAsync(c->prefix_buf, prefix, (size_t)N * PS * 4, hipMemcpyDeviceToDevice, s));
+  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, 64 * sizeof(unsigned), s));   // tickets start at zero whatever happened before
   // algorithmic work of a KV-cached decode: per token 4 layers x 12 E^2 MACs + the tied LM head;
   // bytes = every fp32 weight read once per step
   const double layer_params = (double)c->cfg.dec_layers * 12.0 * E * E, head_params = (double)c->cfg.dec_vocab * E;

@@ -16,8 +16,10 @@
 //     W' = W * ln_w (per input channel), c_j = sum_k W'_jk, d_j = sum_k ln_b_k W_jk + b_j precomputed at load
 //     time; mu, r come from the x values the waves load anyway (one LDS reduction), so no LayerNorm kernel
 //     and no normalised copy of x exist.
-//   * the GEMMs that end a residual branch (attn.c_proj, mlp.c_proj) cover the full K in one workgroup
-//     (4 or 16 waves) and add bias + result into the residual stream in place (deterministic, no atomics).
+//   * the GEMMs that end a residual branch (attn.c_proj, mlp.c_proj) add bias + result into the residual
+//     stream in place; mlp.c_proj (K = 3072) is split over 4 workgroups per column group whose partial tiles
+//     are summed in slice order by the last arriver (ticket counter, agent-scope release/acquire):
+//     deterministic, no floating-point atomics.
 //   * the LM head never materialises logits: each workgroup reduces its 16 columns to (max, arg-max,
 //     sum-exp) per prefix and k_dec_select merges the 3142 partials into the id / log-prob and writes the
 //     next input embedding.
@@ -37,6 +39,8 @@ namespace pio {
 #define PIO_LMHEAD_CG 1
 #endif
 
+static constexpr int DEC_MAX_COLGROUPS = 64;   // split-K counters / slabs are sized for Nout <= 1024
+
 enum DecEpi { DE_STORE = 0, DE_RESID = 1, DE_GELU = 2, DE_EMBED = 3, DE_ARGMAX = 4 };
 
 __device__ __forceinline__ f32x4 mfma16f(float a, float b, f32x4 c) {
@@ -50,33 +54,36 @@ __device__ __forceinline__ float gelu_new(float x) {
 }
 
 // out[n][j] = epilogue( sum_k X[n][k] * W[j][k] )        W [Nout][K] ([out][in]), X [N][K]
-//   grid = ceil(Nout/16) workgroups of NW waves; K = NW * CPW * 16 (NW = 4: K = 768 or 512; NW = 16: K = 3072).
+//   grid = (ceil(Nout/16), KS) workgroups of 4 waves; each wave owns CPW*16 k's: K = KS * 4 * CPW * 16
+//   (KS = 1: K = 768 or 512; KS = 4: K = 3072).
 //   lane (li = lane&15, kq = lane>>4): B operand W[col0+li][k0 + 16c + 4kq + t], A operand X[16g+li][same k]
 //   (the k order inside a chunk is free as long as A and B agree); C: column li, row 4kq+i.
 //   LN != 0: X is the raw residual stream; the LayerNorm is applied algebraically in the epilogue
 //            (W is pre-scaled by ln_w; cvec / dvec as in the file header).
-template <int RG, int CPW, int NW, int EPI, int LN, int CG>
-__global__ __launch_bounds__(64 * NW) void k_dec_gemm(const float* __restrict__ W, const float* __restrict__ X, int N,
-                                                      int Nout, int K, const float* __restrict__ bias, float* out,
-                                                      const float* __restrict__ extra, const float* __restrict__ cvec,
-                                                      float eps) {
-  extern __shared__ __attribute__((aligned(16))) float red[];      // [NW][RG*CG][256]
-  __shared__ float s_sum[LN ? NW : 1][RG * 16], s_sq[LN ? NW : 1][RG * 16];
+//   KS > 1 : in-launch split-K.  Every k-slice workgroup stores its partial tile to `ws`, publishes it with
+//            an agent-scope release + one relaxed atomic ticket per column group; the workgroup that draws the
+//            last ticket acquires, re-reads ALL KS slabs in slice order (so the sum does not depend on which
+//            workgroup was last: deterministic) and runs the epilogue; it also re-arms the counter.
+template <int RG, int CPW, int KS, int EPI, int LN>
+__global__ __launch_bounds__(256) void k_dec_gemm(const float* __restrict__ W, const float* __restrict__ X, int N,
+                                                  int Nout, int K, const float* __restrict__ bias, float* out,
+                                                  const float* __restrict__ extra, const float* __restrict__ cvec,
+                                                  float eps, float* ws, unsigned* cnt) {
+  __shared__ __attribute__((aligned(16))) float red[4 * RG * 256];
+  __shared__ float s_sum[LN ? 4 : 1][RG * 16], s_sq[LN ? 4 : 1][RG * 16];
+  __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
-  const int col0 = blockIdx.x * (16 * CG);
-  const int k0 = wid * (16 * CPW) + 4 * kq;
-  float4 w4[CG][CPW];
+  const int col0 = blockIdx.x * 16;
+  const int j = col0 + li;
+  const int jc = j < Nout ? j : Nout - 1;
+  const int k0 = (blockIdx.y * 4 + wid) * (16 * CPW) + 4 * kq;
+  const float* wp = W + (size_t)jc * K + k0;
+  float4 w4[CPW];
 #pragma unroll
-  for (int q = 0; q < CG; ++q) {
-    int col = col0 + 16 * q + li;
-    col = col < Nout ? col : Nout - 1;
-    const float* wp = W + (size_t)col * K + k0;
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) w4[q][c] = *(const float4*)(wp + 16 * c);   // the HBM stream: all in flight
-  }
+  for (int c = 0; c < CPW; ++c) w4[c] = *(const float4*)(wp + 16 * c);       // the HBM stream: all in flight
   __builtin_amdgcn_sched_barrier(0);   // keep hipcc from sinking the loads next to their MFMAs (2 in flight)
-  f32x4 acc[RG][CG];
+  f32x4 acc[RG];
 #pragma unroll
   for (int g = 0; g < RG; ++g) {
     int n = g * 16 + li;
@@ -86,56 +93,93 @@ __global__ __launch_bounds__(64 * NW) void k_dec_gemm(const float* __restrict__ 
 #pragma unroll
     for (int c = 0; c < CPW; ++c) x4[c] = PIO_DABL_NOX ? make_float4(0.5f, 0.25f, 1.f, 2.f) : *(const float4*)(xp + 16 * c);   // activations: L2-resident
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 a[CG];
-#pragma unroll
-    for (int q = 0; q < CG; ++q) a[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = (f32x4){0.f, 0.f, 0.f, 0.f};   // two independent MFMA chains
     float sx = 0.f, sq = 0.f;
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-#pragma unroll
-      for (int q = 0; q < CG; ++q) {
-        if (PIO_DABL_NOMFMA) { a[q][0] += x4[c].x * w4[q][c].x + x4[c].y * w4[q][c].y + x4[c].z * w4[q][c].z + x4[c].w * w4[q][c].w; continue; }
-        a[q] = mfma16f(x4[c].x, w4[q][c].x, a[q]);
-        a[q] = mfma16f(x4[c].y, w4[q][c].y, a[q]);
-        a[q] = mfma16f(x4[c].z, w4[q][c].z, a[q]);
-        a[q] = mfma16f(x4[c].w, w4[q][c].w, a[q]);
-      }
+    for (int c = 0; c < CPW; c += 2) {
+      a0 = mfma16f(x4[c].x, w4[c].x, a0);  a1 = mfma16f(x4[c + 1].x, w4[c + 1].x, a1);
+      a0 = mfma16f(x4[c].y, w4[c].y, a0);  a1 = mfma16f(x4[c + 1].y, w4[c + 1].y, a1);
+      a0 = mfma16f(x4[c].z, w4[c].z, a0);  a1 = mfma16f(x4[c + 1].z, w4[c + 1].z, a1);
+      a0 = mfma16f(x4[c].w, w4[c].w, a0);  a1 = mfma16f(x4[c + 1].w, w4[c + 1].w, a1);
       if (LN) {
-        sx += (x4[c].x + x4[c].y) + (x4[c].z + x4[c].w);
-        sq += (x4[c].x * x4[c].x + x4[c].y * x4[c].y) + (x4[c].z * x4[c].z + x4[c].w * x4[c].w);
+        sx += ((x4[c].x + x4[c].y) + (x4[c].z + x4[c].w)) + ((x4[c + 1].x + x4[c + 1].y) + (x4[c + 1].z + x4[c + 1].w));
+        sq += ((x4[c].x * x4[c].x + x4[c].y * x4[c].y) + (x4[c].z * x4[c].z + x4[c].w * x4[c].w)) +
+              ((x4[c + 1].x * x4[c + 1].x + x4[c + 1].y * x4[c + 1].y) + (x4[c + 1].z * x4[c + 1].z + x4[c + 1].w * x4[c + 1].w));
       }
     }
-#pragma unroll
-    for (int q = 0; q < CG; ++q) acc[g][q] = a[q];
+    acc[g] = a0 + a1;
     if (LN) {   // row statistics of x: this lane holds 4*CPW values of row 16g+li; sum the 4 kq groups
       sx += __shfl_xor(sx, 16); sx += __shfl_xor(sx, 32);
       sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
       if (kq == 0) { s_sum[wid][g * 16 + li] = sx; s_sq[wid][g * 16 + li] = sq; }
     }
   }
+  // epilogue vectors: issued before the LDS reduction so their latency overlaps it
+  const float bj = EPI == DE_ARGMAX && !LN ? 0.f : bias[jc];
+  const float cj = LN ? cvec[jc] : 0.f;
+  const float ej = EPI == DE_EMBED ? extra[jc] : 0.f;
 #pragma unroll
-  for (int g = 0; g < RG; ++g)
-#pragma unroll
-    for (int q = 0; q < CG; ++q) *(f32x4*)(red + ((wid * RG * CG + g * CG + q) * 64 + lane) * 4) = acc[g][q];
+  for (int g = 0; g < RG; ++g) *(f32x4*)(red + ((wid * RG + g) * 64 + lane) * 4) = acc[g];
   __syncthreads();
-  for (int gq = wid; gq < RG * CG; gq += NW) {
-    const int g = gq / CG, q = gq - g * CG;
-    f32x4 s = *(const f32x4*)(red + ((0 * RG * CG + gq) * 64 + lane) * 4);
+  f32x4 sums[(RG + 3) / 4];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) s += *(const f32x4*)(red + ((w * RG * CG + gq) * 64 + lane) * 4);
-    const int j = col0 + 16 * q + li;
-    const int jc = j < Nout ? j : Nout - 1;
+  for (int gi = 0; gi < (RG + 3) / 4; ++gi) {
+    const int g = wid + 4 * gi;
+    if (g < RG) {
+      f32x4 s = *(const f32x4*)(red + ((0 * RG + g) * 64 + lane) * 4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) s += *(const f32x4*)(red + ((w * RG + g) * 64 + lane) * 4);
+      sums[gi] = s;
+    }
+  }
+  if constexpr (KS > 1) {
+    float* slab = ws + ((size_t)blockIdx.x * KS) * RG * 256;
+#pragma unroll
+    for (int gi = 0; gi < (RG + 3) / 4; ++gi) {
+      const int g = wid + 4 * gi;
+      if (g < RG) *(f32x4*)(slab + ((size_t)blockIdx.y * RG + g) * 256 + lane * 4) = sums[gi];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its stores
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the release's write-back has completed
+      const unsigned t = __hip_atomic_fetch_add(cnt + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == (unsigned)(KS - 1));
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(cnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    }
+    __syncthreads();
+#pragma unroll
+    for (int gi = 0; gi < (RG + 3) / 4; ++gi) {
+      const int g = wid + 4 * gi;
+      if (g < RG) {
+        f32x4 s = *(const f32x4*)(slab + ((size_t)0 * RG + g) * 256 + lane * 4);
+#pragma unroll
+        for (int y = 1; y < KS; ++y) s += *(const f32x4*)(slab + ((size_t)y * RG + g) * 256 + lane * 4);
+        sums[gi] = s;
+      }
+    }
+  }
+#pragma unroll
+  for (int gi = 0; gi < (RG + 3) / 4; ++gi) {
+    const int g = wid + 4 * gi;
+    if (g >= RG) continue;
+    f32x4 s = sums[gi];
     if (LN) {   // s_i <- r_n (s_i - mu_n c_j) + d_j  for row n = 16g + 4kq + i
-      const float cj = cvec[jc], dj = bias[jc];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rr = g * 16 + 4 * kq + i;
-        float tx = 0.f, tq = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { tx += s_sum[w][rr]; tq += s_sq[w][rr]; }
+        const float tx = (s_sum[0][rr] + s_sum[1][rr]) + (s_sum[2][rr] + s_sum[3][rr]);
+        const float tq = (s_sq[0][rr] + s_sq[1][rr]) + (s_sq[2][rr] + s_sq[3][rr]);
         const float mu = tx / (float)K;
         const float var = fmaxf(tq / (float)K - mu * mu, 0.f);
-        s[i] = rsqrtf(var + eps) * (s[i] - mu * cj) + dj;
+        s[i] = rsqrtf(var + eps) * (s[i] - mu * cj) + bj;
       }
     }
     if constexpr (EPI == DE_ARGMAX) {
@@ -156,7 +200,7 @@ __global__ __launch_bounds__(64 * NW) void k_dec_gemm(const float* __restrict__ 
         for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o);
         const int n = g * 16 + 4 * kq + i;
         if (li == 0 && n < N) {
-          float* p = out + ((size_t)(blockIdx.x * CG + q) * N + n) * 4;
+          float* p = out + ((size_t)blockIdx.x * N + n) * 4;
           p[0] = mx; p[1] = __int_as_float(idx); p[2] = se;
         }
       }
@@ -166,12 +210,12 @@ __global__ __launch_bounds__(64 * NW) void k_dec_gemm(const float* __restrict__ 
       for (int i = 0; i < 4; ++i) {
         const int n = g * 16 + 4 * kq + i;
         if (n >= N) continue;
-        const float v = LN ? s[i] : s[i] + bias[j];     // LN: the bias is already inside d_j
+        const float v = LN ? s[i] : s[i] + bj;          // LN: the bias is already inside d_j
         float* o = out + (size_t)n * Nout + j;
         if constexpr (EPI == DE_STORE) *o = v;
         else if constexpr (EPI == DE_RESID) *o += v;    // each element has exactly one owner: in place is safe
         else if constexpr (EPI == DE_GELU) *o = gelu_new(v);
-        else if constexpr (EPI == DE_EMBED) *o = v + extra[j];
+        else if constexpr (EPI == DE_EMBED) *o = v + ej;
       }
     }
   }
@@ -297,38 +341,34 @@ __global__ __launch_bounds__(256) void k_dec_select(const float* __restrict__ pa
   }
 }
 
-template <int CPW, int NW, int EPI, int LN, int CG>
+template <int CPW, int KS, int EPI, int LN>
 static hipError_t dec_gemm_rg(const float* W, const float* X, int N, int Nout, int K, const float* bias, float* out,
-                              const float* extra, const float* cvec, float eps, hipStream_t s) {
-  const dim3 grid(ceil_div(Nout, 16 * CG)), block(64 * NW);
+                              const float* extra, const float* cvec, float eps, float* ws, unsigned* cnt,
+                              hipStream_t s) {
+  const dim3 grid(ceil_div(Nout, 16), KS), block(256);
   const int rg = ceil_div(N, 16);
-#define PIO_DG(R) hipLaunchKernelGGL((k_dec_gemm<R, CPW, NW, EPI, LN, CG>), grid, block, NW * R * CG * 1024, s, W, X, N, Nout, K, bias, out, extra, cvec, eps)
+#define PIO_DG(R) hipLaunchKernelGGL((k_dec_gemm<R, CPW, KS, EPI, LN>), grid, block, 0, s, W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt)
   if (rg <= 1) PIO_DG(1);
   else if (rg <= 2) PIO_DG(2);
   else if (rg <= 4) PIO_DG(4);
-  else if (NW == 4 && CG == 1) PIO_DG(8);
-  else return hipErrorInvalidValue;      // 16-wave / 2-column-group workgroups are built for <= 64 prefixes
+  else return hipErrorInvalidValue;
 #undef PIO_DG
   return hipGetLastError();
 }
 
-// K = 768 (4 waves x 12 chunks), 512 (4 x 8) or 3072 (16 x 12)
+// K = 768 (4 waves x 12 chunks), 512 (4 x 8) or 3072 (4 workgroups x 4 waves x 12, split-K with `ws` / `cnt`)
 template <int EPI, int LN>
 static hipError_t dec_gemm(const float* W, const float* X, int N, int Nout, int K, const float* bias, float* out,
-                           const float* extra, const float* cvec, float eps, hipStream_t s) {
-  if (N < 1 || N > 128) return hipErrorInvalidValue;
-  constexpr int CG = EPI == DE_ARGMAX ? PIO_LMHEAD_CG : 1;   // LM head: 32 columns per workgroup halve the re-reads of x
-  if (K == 768) return dec_gemm_rg<12, 4, EPI, LN, CG>(W, X, N, Nout, K, bias, out, extra, cvec, eps, s);
-  if (K == 512) return dec_gemm_rg<8, 4, EPI, LN, CG>(W, X, N, Nout, K, bias, out, extra, cvec, eps, s);
-  if (K == 3072) return dec_gemm_rg<12, 16, EPI, LN, CG>(W, X, N, Nout, K, bias, out, extra, cvec, eps, s);
+                           const float* extra, const float* cvec, float eps, float* ws, unsigned* cnt, hipStream_t s) {
+  if (N < 1 || N > 64) return hipErrorInvalidValue;
+  if (K == 768) return dec_gemm_rg<12, 1, EPI, LN>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);
+  if (K == 512) return dec_gemm_rg<8, 1, EPI, LN>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);
+  if (K == 3072 && EPI == DE_RESID && !LN && ws != nullptr && cnt != nullptr && Nout <= 16 * DEC_MAX_COLGROUPS)
+    return dec_gemm_rg<12, 4, DE_RESID, 0>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);
   return hipErrorInvalidValue;
 }
 
-hipError_t decoder_init() {
-  // the 16-wave, 4-row-group instantiation needs 64 KiB of dynamic LDS
-  return hipFuncSetAttribute((const void*)k_dec_gemm<4, 12, 16, DE_RESID, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             16 * 4 * 1024);
-}
+hipError_t decoder_init() { return hipSuccess; }   // no function attributes needed any more
 
 #define PIO_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
 
@@ -339,7 +379,7 @@ hipError_t decoder_init() {
 hipError_t launch_lmhead(const float* W, const float* X, int N, int V, int E, const float* dvec, const float* cvec,
                          float eps, float* part, int* nblk, hipStream_t s) {
   *nblk = ceil_div(V, 16);
-  return dec_gemm<DE_ARGMAX, 1>(W, X, N, V, E, dvec, part, nullptr, cvec, eps, s);
+  return dec_gemm<DE_ARGMAX, 1>(W, X, N, V, E, dvec, part, nullptr, cvec, eps, nullptr, nullptr, s);
 }
 
 hipError_t launch_decode_greedy(const DecoderArgs& a, hipStream_t s) {
@@ -348,18 +388,18 @@ hipError_t launch_decode_greedy(const DecoderArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
   if (ceil_div(a.vocab, 16) > 4096) return hipErrorInvalidValue;
   // step 0 input: clip_project(prefix) + wpe[0]   (decap.py:124; GPT-2 adds wpe to inputs_embeds)
-  PIO_TRY((dec_gemm<DE_EMBED, 0>(a.clip_w, a.prefix, N, E, a.prefix_size, a.clip_b, a.x, a.wpe, nullptr, 0.f, s)));
+  PIO_TRY((dec_gemm<DE_EMBED, 0>(a.clip_w, a.prefix, N, E, a.prefix_size, a.clip_b, a.x, a.wpe, nullptr, 0.f, nullptr, nullptr, s)));
   for (int step = 0; step < a.steps; ++step) {
     for (int l = 0; l < a.layers; ++l) {
       const DecLayerW& w = a.layer[l];
       float* kc = a.kcache + (size_t)l * N * a.max_steps * E;
       float* vc = a.vcache + (size_t)l * N * a.max_steps * E;
-      PIO_TRY((dec_gemm<DE_STORE, 1>(w.attn_w, a.x, N, 3 * E, E, w.attn_d, a.qkv, nullptr, w.attn_c, a.eps, s)));
+      PIO_TRY((dec_gemm<DE_STORE, 1>(w.attn_w, a.x, N, 3 * E, E, w.attn_d, a.qkv, nullptr, w.attn_c, a.eps, nullptr, nullptr, s)));
       hipLaunchKernelGGL(k_dec_attention, dim3(N * a.heads), dim3(256), 0, s, a.qkv, kc, vc, E, a.heads, step,
                          a.max_steps, a.att);
-      PIO_TRY((dec_gemm<DE_RESID, 0>(w.proj_w, a.att, N, E, E, w.proj_b, a.x, nullptr, nullptr, 0.f, s)));
-      PIO_TRY((dec_gemm<DE_GELU, 1>(w.fc_w, a.x, N, 4 * E, E, w.fc_d, a.hid, nullptr, w.fc_c, a.eps, s)));
-      PIO_TRY((dec_gemm<DE_RESID, 0>(w.fc2_w, a.hid, N, E, 4 * E, w.fc2_b, a.x, nullptr, nullptr, 0.f, s)));
+      PIO_TRY((dec_gemm<DE_RESID, 0>(w.proj_w, a.att, N, E, E, w.proj_b, a.x, nullptr, nullptr, 0.f, nullptr, nullptr, s)));
+      PIO_TRY((dec_gemm<DE_GELU, 1>(w.fc_w, a.x, N, 4 * E, E, w.fc_d, a.hid, nullptr, w.fc_c, a.eps, nullptr, nullptr, s)));
+      PIO_TRY((dec_gemm<DE_RESID, 0>(w.fc2_w, a.hid, N, E, 4 * E, w.fc2_b, a.x, nullptr, nullptr, 0.f, a.splitk_ws, a.splitk_cnt, s)));
     }
     int nblk = 0;
     PIO_TRY(launch_lmhead(a.head_w, a.x, N, a.vocab, E, a.head_d, a.head_c, a.eps, a.logits, &nblk, s));

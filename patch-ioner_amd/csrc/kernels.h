@@ -116,6 +116,8 @@ struct DecoderArgs {
   float* kcache; // [layers][N][max_steps][E]
   float* vcache;
   int max_steps;
+  float* splitk_ws;       // [64 column groups][4 k-slices][4 row groups][256] partial tiles
+  unsigned* splitk_cnt;   // [64] arrival tickets (zero between launches)
   float* logits; // [ceil(V/16)][N][4] per-workgroup (max, arg-max, sum-exp) partials of the LM head
   int32_t* ids;      // [N][steps]
   float* logprob;    // [N][steps] or null

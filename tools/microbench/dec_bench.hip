@@ -9,6 +9,9 @@
 using namespace pio;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
+__global__ void k_empty(float* p) { if (p == nullptr) *p = 0.f; }
+__global__ void k_touch(float* p) { p[blockIdx.x * 256 + threadIdx.x] += 1.0f; }
+
 template <typename F>
 static float time_chain(F f, int iter = 200) {
   hipEvent_t e0, e1;
@@ -27,7 +30,8 @@ int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 16;
   const int E = 768, V = 50257, S = 32, heads = 4;
   float *w_qkv, *w_proj, *w_fc, *w_fc2, *w_head, *x, *qkv, *att, *hid, *part, *bias, *cvec, *kc, *vc, *wte, *wpe;
-  int32_t* ids; float* lp;
+  int32_t* ids; float* lp; float* ws; unsigned* cnt;
+  hipMalloc(&ws, 64 * 4 * 4 * 256 * 4); hipMalloc(&cnt, 256); hipMemset(cnt, 0, 256);
   CK(hipMalloc(&w_qkv, (size_t)3 * E * E * 4)); CK(hipMalloc(&w_proj, (size_t)E * E * 4));
   CK(hipMalloc(&w_fc, (size_t)4 * E * E * 4)); CK(hipMalloc(&w_fc2, (size_t)4 * E * E * 4));
   CK(hipMalloc(&w_head, (size_t)V * E * 4)); CK(hipMalloc(&wte, (size_t)V * E * 4)); CK(hipMalloc(&wpe, (size_t)1024 * E * 4));
@@ -50,14 +54,26 @@ int main(int argc, char** argv) {
   hipStream_t s = 0;
   int nblk = 0;
   printf("N=%d\n", N);
-  printf("qkv  (LN, store)   %7.2f us\n", time_chain([&] { dec_gemm<DE_STORE, 1>(w_qkv, x, N, 3 * E, E, bias, qkv, nullptr, cvec, 1e-5f, s); }));
+  printf("empty kernel       %7.2f us\n", time_chain([&] { hipLaunchKernelGGL(k_empty, dim3(64), dim3(256), 0, s, x); }, 1000));
+  printf("touch kernel (RMW) %7.2f us\n", time_chain([&] { hipLaunchKernelGGL(k_touch, dim3(48), dim3(256), 0, s, x); }, 1000));
+  {  // the same two kernels replayed from a graph of 200 nodes (what the decode loop uses)
+    hipStream_t cs; hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    for (int which = 0; which < 2; ++which) {
+      hipGraph_t gr; hipGraphExec_t ex;
+      hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+      for (int i = 0; i < 200; ++i) { if (which == 0) hipLaunchKernelGGL(k_empty, dim3(64), dim3(256), 0, cs, x); else hipLaunchKernelGGL(k_touch, dim3(48), dim3(256), 0, cs, x); }
+      hipStreamEndCapture(cs, &gr); hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
+      printf("graph x200 %s  %7.2f us per node\n", which == 0 ? "empty" : "touch", time_chain([&] { hipGraphLaunch(ex, s); }, 20) / 200.f);
+    }
+  }
+  printf("qkv  (LN, store)   %7.2f us\n", time_chain([&] { dec_gemm<DE_STORE, 1>(w_qkv, x, N, 3 * E, E, bias, qkv, nullptr, cvec, 1e-5f, nullptr, nullptr, s); }));
   printf("attention pos=15   %7.2f us\n", time_chain([&] { hipLaunchKernelGGL(k_dec_attention, dim3(N * heads), dim3(256), 0, s, qkv, kc, vc, E, heads, 15, S, att); }));
   printf("attention pos=29   %7.2f us\n", time_chain([&] { hipLaunchKernelGGL(k_dec_attention, dim3(N * heads), dim3(256), 0, s, qkv, kc, vc, E, heads, 29, S, att); }));
-  printf("proj (resid)       %7.2f us\n", time_chain([&] { dec_gemm<DE_RESID, 0>(w_proj, att, N, E, E, bias, x, nullptr, nullptr, 0.f, s); }));
-  printf("fc   (LN, gelu)    %7.2f us\n", time_chain([&] { dec_gemm<DE_GELU, 1>(w_fc, x, N, 4 * E, E, bias, hid, nullptr, cvec, 1e-5f, s); }));
-  printf("fc2  (resid)       %7.2f us\n", time_chain([&] { dec_gemm<DE_RESID, 0>(w_fc2, hid, N, E, 4 * E, bias, x, nullptr, nullptr, 0.f, s); }));
+  printf("proj (resid)       %7.2f us\n", time_chain([&] { dec_gemm<DE_RESID, 0>(w_proj, att, N, E, E, bias, x, nullptr, nullptr, 0.f, ws, cnt, s); }));
+  printf("fc   (LN, gelu)    %7.2f us\n", time_chain([&] { dec_gemm<DE_GELU, 1>(w_fc, x, N, 4 * E, E, bias, hid, nullptr, cvec, 1e-5f, nullptr, nullptr, s); }));
+  printf("fc2  (resid)       %7.2f us\n", time_chain([&] { dec_gemm<DE_RESID, 0>(w_fc2, hid, N, E, 4 * E, bias, x, nullptr, nullptr, 0.f, ws, cnt, s); }));
   printf("lm head (argmax)   %7.2f us\n", time_chain([&] { launch_lmhead(w_head, x, N, V, E, bias, cvec, 1e-5f, part, &nblk, s); }, 50));
-  printf("lm head generic    %7.2f us\n", time_chain([&] { dec_gemm<DE_ARGMAX, 1>(w_head, x, N, V, E, bias, part, nullptr, cvec, 1e-5f, s); }, 50));
+  printf("lm head generic    %7.2f us\n", time_chain([&] { dec_gemm<DE_ARGMAX, 1>(w_head, x, N, V, E, bias, part, nullptr, cvec, 1e-5f, nullptr, nullptr, s); }, 50));
   printf("select             %7.2f us\n", time_chain([&] { hipLaunchKernelGGL(k_dec_select, dim3(N), dim3(256), 0, s, part, nblk, N, E, 3, S, wte, wpe, ids, lp, x); }));
   CK(hipDeviceSynchronize());
   return 0;
