@@ -67,21 +67,33 @@ __global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_region_reduce(const float* __restrict__ tokens, int T, int G, int D, int n2,
                                                        const float* __restrict__ w, const int32_t* img_index,
                                                        float scale, float* out) {
-  const int r = blockIdx.x;
+  // grid (R, ceil(D/256)): lane = one float4 column of a 256-channel slab; the 4 waves split the patches
+  // (p = wave, wave+4, ...) with the weight row staged in LDS, then meet in LDS.
+  __shared__ float s_w[1536];
+  __shared__ __attribute__((aligned(16))) float s_acc[4][256];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int img = img_index ? img_index[r] : r;
-  const int c = threadIdx.x;
-  if (c * 4 >= D) return;
-  const float* wr = w + (size_t)r * n2;
-  const float4* base = (const float4*)(tokens + ((size_t)img * T + G) * D) + c;
+  for (int p = tid; p < n2; p += 256) s_w[p] = w[(size_t)r * n2 + p];
+  __syncthreads();
+  const int c = blockIdx.y * 64 + lane;            // float4 column
+  const bool live = c * 4 < D;
+  const float4* base = (const float4*)(tokens + ((size_t)img * T + G) * D) + (live ? c : 0);
   const int stride = D >> 2;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int p = 0; p < n2; ++p) {
-    const float wv = wr[p];
-    if (wv == 0.f) continue;
+  for (int p = wid; p < n2; p += 4) {
+    const float wv = s_w[p];
+    if (wv == 0.f) continue;                        // wave-uniform: regions are small
     const float4 t = base[(size_t)p * stride];
     acc.x += wv * t.x; acc.y += wv * t.y; acc.z += wv * t.z; acc.w += wv * t.w;
   }
-  ((float4*)(out + (size_t)r * D))[c] = make_float4(acc.x * scale, acc.y * scale, acc.z * scale, acc.w * scale);
+  *(float4*)&s_acc[wid][4 * lane] = acc;
+  __syncthreads();
+  if (wid == 0 && live) {
+    const float4 a0 = *(const float4*)&s_acc[0][4 * lane], a1 = *(const float4*)&s_acc[1][4 * lane];
+    const float4 a2 = *(const float4*)&s_acc[2][4 * lane], a3 = *(const float4*)&s_acc[3][4 * lane];
+    ((float4*)(out + (size_t)r * D))[c] = make_float4(((a0.x + a1.x) + (a2.x + a3.x)) * scale, ((a0.y + a1.y) + (a2.y + a3.y)) * scale,
+                                                     ((a0.z + a1.z) + (a2.z + a3.z)) * scale, ((a0.w + a1.w) + (a2.w + a3.w)) * scale);
+  }
 }
 
 __global__ __launch_bounds__(64) void k_trace_grids(const double* __restrict__ xy, const int32_t* __restrict__ offs,
@@ -257,8 +269,8 @@ hipError_t launch_bbox_weights(const int32_t* boxes, int B, int NB, int n, int m
 
 hipError_t launch_region_reduce(const float* tokens, int T, int G, int D, int n2, const float* weights,
                                 const int32_t* img_index, int R, float scale, float* out, hipStream_t s) {
-  if (D % 4 != 0 || D > 1024 || R <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_region_reduce, dim3(R), dim3(256), 0, s, tokens, T, G, D, n2, weights, img_index, scale, out);
+  if (D % 4 != 0 || D > 1024 || R <= 0 || n2 > 1536) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_region_reduce, dim3(R, ceil_div(D, 256)), dim3(256), 0, s, tokens, T, G, D, n2, weights, img_index, scale, out);
   return hipGetLastError();
 }
 

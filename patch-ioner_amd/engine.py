@@ -51,6 +51,8 @@ class Engine:
         self.num_weights = 0
         self.bank_rows = 0
         self._finalized = False
+        self._stage_host = None
+        self._stage_dev = None
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
@@ -148,19 +150,26 @@ class Engine:
 
     # ------------------------------------------------------------------ a6 traces
     def trace_grids(self, traces: Sequence[Sequence[dict]]) -> torch.Tensor:
+        """map_traces_to_grid for a batch: points packed CSR-style into ONE pinned staging buffer (x, y as
+        float64 followed by the int32 offsets) and sent with one asynchronous copy; the counting runs on
+        the device."""
         B = len(traces)
-        offs = np.zeros(B + 1, dtype=np.int32)
-        pts = []
-        for i, tr in enumerate(traces):
-            for p in tr:
-                pts.append((float(p["x"]), float(p["y"])))
-            offs[i + 1] = len(pts)
-        xy = torch.tensor(pts, dtype=torch.float64).reshape(-1, 2) if pts else torch.zeros(0, 2, dtype=torch.float64)
-        xy_d = xy.to(self.device).contiguous()
-        offs_d = torch.from_numpy(offs).to(self.device)
+        xy = np.array([(p["x"], p["y"]) for tr in traces for p in tr], dtype=np.float64).reshape(-1, 2)
+        npts = xy.shape[0]
+        nbytes = npts * 16 + (B + 1) * 4
+        if self._stage_host is None or self._stage_host.numel() < nbytes:
+            cap = max(1 << 16, 2 * nbytes)
+            self._stage_host = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            self._stage_dev = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        host = self._stage_host.numpy()
+        host[: npts * 16].view(np.float64)[:] = xy.reshape(-1)
+        offs = host[npts * 16: nbytes].view(np.int32)
+        offs[0] = 0
+        np.cumsum([len(tr) for tr in traces], out=offs[1:])
+        self._stage_dev[:nbytes].copy_(self._stage_host[:nbytes], non_blocking=True)
+        base = self._stage_dev.data_ptr()
         grids = torch.empty(B, self.n, self.n, device=self.device, dtype=torch.float32)
-        check(self.lib.pio_trace_grids(self.h, ptr(xy_d) if len(pts) else None, ptr(offs_d), B, len(pts), ptr(grids),
-                                       _stream()))
+        check(self.lib.pio_trace_grids(self.h, base if npts else None, base + npts * 16, B, npts, ptr(grids), _stream()))
         return grids
 
     # ------------------------------------------------------------------ a7 boxes
