@@ -28,7 +28,8 @@ MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
-def build_model(device_index: int):
+def build_models(device_index: int, count: int):
+    """`count` identical model instances (own workspaces / decode graphs / bank copy each) for `count` batches in flight."""
     from patchioner_amd import Patchioner, weights as W
     g = torch.Generator(device="cuda").manual_seed(6)
     bank = torch.empty(BANK_ROWS, 768, device="cuda", dtype=torch.float32)
@@ -39,10 +40,10 @@ def build_model(device_index: int):
            "prefix_size": 768, "linear_talk2dino": False, "support_memory_size": BANK_ROWS,
            "dino_model": "dinov2_vitb14_reg", "normalize": True, "resize_dim": CROP, "crop_dim": CROP,
            "max_batch": BATCH, "max_prefixes": 64}
-    m = Patchioner.from_config(cfg, device="cuda:%d" % device_index)
+    models = [Patchioner.from_config(cfg, device="cuda:%d" % device_index) for _ in range(count)]
     del bank
     torch.cuda.empty_cache()
-    return m
+    return models
 
 
 def make_inputs():
@@ -88,6 +89,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("PIO_BENCH_IN_FLIGHT", "1")),
+                    help="batches kept in flight per GPU (each on its own model instance and stream); 1 = the "
+                         "reference's synchronous forward")
     args = ap.parse_args()
 
     from patchioner_amd import dist as pdist
@@ -98,7 +102,10 @@ def main():
     torch.set_grad_enabled(False)
     import torch.distributed as dist
 
-    model = build_model(local)
+    P = max(1, args.in_flight)
+    models = build_models(local, P)
+    model = models[0]
+    streams = [torch.cuda.Stream() for _ in range(P)]
     imgs, traces = make_inputs()
 
     def step():
@@ -106,17 +113,37 @@ def main():
         ids = pdist.all_gather_equal_ids(model.last_ids)       # the path's only exchange: final captions' ids
         return outs, ids
 
+    def run_steps(n):
+        """n forwards; with P > 1, P of them are in flight (model instance i % P on stream i % P)"""
+        if P == 1:
+            for _ in range(n):
+                outs, ids = step()
+            return outs, ids
+        from collections import deque
+        pend = deque()
+        outs = ids = None
+        for i in range(n):
+            if len(pend) == P:
+                h = pend.popleft()
+                outs = h.result()
+                ids = pdist.all_gather_equal_ids(h.ids("trace_capts"))
+            pend.append(models[i % P].forward_async(imgs, stream=streams[i % P], get_cls_capt=False, traces=traces,
+                                                    gaussian_avg=True))
+        while pend:
+            h = pend.popleft()
+            outs = h.result()
+            ids = pdist.all_gather_equal_ids(h.ids("trace_capts"))
+        return outs, ids
+
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(max(args.warmup, P))
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        outs, ids = step()
+    outs, ids = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     # Second, identical region with the live HIP-event brackets on (pio_profile_*): every bracketed launch gets
@@ -157,7 +184,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
             "config": {"workload": "talk2dino_decap_COCO, ViT-B/14-reg 224^2, batch 16/GPU, caption_from=patches "
                                    "(one 16-patch trace region per image), bank 591753x768 fp32, 30-step greedy decode",
-                       "global_batch": BATCH * world, "parallelism": "dp%d (image shards, ids all-gather)" % world},
+                       "global_batch": BATCH * world, "parallelism": "dp%d (image shards, ids all-gather)" % world, "batches_in_flight_per_gpu": P},
             "roofline": {"kernel": "k_vit_gemm (fp16 MFMA 32x32x16, 60+1 launches/step)", "bound": "mfma",
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,

@@ -194,6 +194,7 @@ class Patchioner(nn.Module):
             self.im_proj = None
         self.tokenizer = ClipDetokenizer()
         self.last_ids = None
+        self._defer = False
         self.dino = self.engine     # callers test `model.dino is not None`
         # one zero-size parameter so `next(model.parameters()).device` works as in the reference
         self._anchor = nn.Parameter(torch.zeros(0, device=self._device), requires_grad=False)
@@ -473,10 +474,70 @@ class Patchioner(nn.Module):
             prefix = eng.revert_transformation(prefix)
         ids, lp = eng.decode_greedy(prefix, steps=30, want_logprob=compute_scores)
         self.last_ids = ids
+        if self._defer:
+            if compute_scores:
+                raise NotImplementedError("forward_async does not defer score lists; call forward() for compute_scores")
+            return _PendingCaptions(ids, self.tokenizer, self.decoding_method)
         outputs = self.tokenizer.batch_captions(ids.cpu().tolist(), decoding_method=self.decoding_method)
         if compute_scores:
             return outputs, torch.exp(lp.sum(dim=-1)).cpu().numpy().tolist()
         return outputs
 
+    # ------------------------------------------------------------------------------------------
+    def forward_async(self, imgs, stream: Optional["torch.cuda.Stream"] = None, **kwargs) -> "PendingForward":
+        """Enqueue a whole forward on `stream` without waiting for the GPU: same arguments as ``forward`` (the
+        flat caption outputs only: cls / avg_self_attn / avg_patch / trace / set_controllable captions), returns a
+        handle whose ``result()`` gives exactly what ``forward`` would have returned.  Several model instances,
+        each on its own stream, can keep several batches in flight (the decode of one batch is a chain of small
+        latency-bound kernels that leaves most CUs idle, so it overlaps with the next batch's ViT)."""
+        for k in ("bboxes", "get_attn_heads_capt", "get_patch_capts", "get_register_capts"):
+            if kwargs.get(k) not in (None, False):
+                if not (k == "bboxes" and kwargs.get("get_controllable_capts")):
+                    raise NotImplementedError("forward_async supports the flat caption outputs only (%s given)" % k)
+        stream = stream or torch.cuda.current_stream()
+        self._defer = True
+        try:
+            with torch.cuda.stream(stream):
+                outs = self.forward(imgs, **kwargs)
+                for v in outs.values():
+                    if isinstance(v, _PendingCaptions):
+                        v.start_copy()
+                ev = torch.cuda.Event()
+                ev.record(stream)
+        finally:
+            self._defer = False
+        return PendingForward(outs, ev)
+
     def __len__(self):
         return self.engine.num_weights
+
+
+class _PendingCaptions:
+    """Greedy ids still on the device; resolved to the reference's list-of-strings on demand."""
+
+    def __init__(self, ids_dev, tokenizer, decoding_method):
+        self.ids_dev, self.tokenizer, self.decoding_method = ids_dev, tokenizer, decoding_method
+        self.ids_host = None
+
+    def start_copy(self):
+        self.ids_host = torch.empty(self.ids_dev.shape, dtype=self.ids_dev.dtype).pin_memory()
+        self.ids_host.copy_(self.ids_dev, non_blocking=True)
+
+    def resolve(self):
+        return self.tokenizer.batch_captions(self.ids_host.tolist(), decoding_method=self.decoding_method)
+
+
+class PendingForward:
+    def __init__(self, outs, event):
+        self._outs, self._event = outs, event
+
+    def done(self) -> bool:
+        return self._event.query()
+
+    def ids(self, key: str):
+        """device tensor of the greedy ids behind output `key` (valid once result() or done())"""
+        return self._outs[key].ids_dev
+
+    def result(self) -> dict:
+        self._event.synchronize()
+        return {k: (v.resolve() if isinstance(v, _PendingCaptions) else v) for k, v in self._outs.items()}
