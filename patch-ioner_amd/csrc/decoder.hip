@@ -35,6 +35,12 @@ namespace pio {
 #ifndef PIO_DABL_NOMFMA
 #define PIO_DABL_NOMFMA 0
 #endif
+// minimum waves per SIMD requested for k_dec_gemm.  (5 => <= 96 VGPRs would let decode waves sit beside two
+// 208-register ViT GEMM waves when batches are pipelined on several streams; measured: it spills and is slower
+// both alone, 6.6 vs 5.8 ms per 30 steps, and pipelined, 2586 vs 2984 captions/s.)
+#ifndef PIO_DEC_GEMM_WAVES
+#define PIO_DEC_GEMM_WAVES 2
+#endif
 #ifndef PIO_LMHEAD_CG
 #define PIO_LMHEAD_CG 1
 #endif
@@ -65,7 +71,7 @@ __device__ __forceinline__ float gelu_new(float x) {
 //            last ticket acquires, re-reads ALL KS slabs in slice order (so the sum does not depend on which
 //            workgroup was last: deterministic) and runs the epilogue; it also re-arms the counter.
 template <int RG, int CPW, int KS, int EPI, int LN>
-__global__ __launch_bounds__(256) void k_dec_gemm(const float* __restrict__ W, const float* __restrict__ X, int N,
+__global__ __launch_bounds__(256, PIO_DEC_GEMM_WAVES) void k_dec_gemm(const float* __restrict__ W, const float* __restrict__ X, int N,
                                                   int Nout, int K, const float* __restrict__ bias, float* out,
                                                   const float* __restrict__ extra, const float* __restrict__ cvec,
                                                   float eps, float* ws, unsigned* cnt) {
@@ -89,24 +95,32 @@ __global__ __launch_bounds__(256) void k_dec_gemm(const float* __restrict__ W, c
     int n = g * 16 + li;
     n = n < N ? n : N - 1;
     const float* xp = X + (size_t)n * K + k0;
-    float4 x4[CPW];
+    // activations (L2-resident), requested in two halves right behind the weight stream
+    constexpr int HC = CPW / 2;
+    float4 xa[HC], xb[HC];
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) x4[c] = PIO_DABL_NOX ? make_float4(0.5f, 0.25f, 1.f, 2.f) : *(const float4*)(xp + 16 * c);   // activations: L2-resident
+    for (int c = 0; c < HC; ++c) xa[c] = PIO_DABL_NOX ? make_float4(0.5f, 0.25f, 1.f, 2.f) : *(const float4*)(xp + 16 * c);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < HC; ++c) xb[c] = PIO_DABL_NOX ? make_float4(0.5f, 0.25f, 1.f, 2.f) : *(const float4*)(xp + 16 * (HC + c));
     __builtin_amdgcn_sched_barrier(0);
     f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = (f32x4){0.f, 0.f, 0.f, 0.f};   // two independent MFMA chains
     float sx = 0.f, sq = 0.f;
-#pragma unroll
-    for (int c = 0; c < CPW; c += 2) {
-      a0 = mfma16f(x4[c].x, w4[c].x, a0);  a1 = mfma16f(x4[c + 1].x, w4[c + 1].x, a1);
-      a0 = mfma16f(x4[c].y, w4[c].y, a0);  a1 = mfma16f(x4[c + 1].y, w4[c + 1].y, a1);
-      a0 = mfma16f(x4[c].z, w4[c].z, a0);  a1 = mfma16f(x4[c + 1].z, w4[c + 1].z, a1);
-      a0 = mfma16f(x4[c].w, w4[c].w, a0);  a1 = mfma16f(x4[c + 1].w, w4[c + 1].w, a1);
-      if (LN) {
-        sx += ((x4[c].x + x4[c].y) + (x4[c].z + x4[c].w)) + ((x4[c + 1].x + x4[c + 1].y) + (x4[c + 1].z + x4[c + 1].w));
-        sq += ((x4[c].x * x4[c].x + x4[c].y * x4[c].y) + (x4[c].z * x4[c].z + x4[c].w * x4[c].w)) +
-              ((x4[c + 1].x * x4[c + 1].x + x4[c + 1].y * x4[c + 1].y) + (x4[c + 1].z * x4[c + 1].z + x4[c + 1].w * x4[c + 1].w));
-      }
+#define PIO_HALF(xh, wofs)                                                                                     \
+    _Pragma("unroll") for (int c = 0; c < HC; c += 2) {                                                          \
+      a0 = mfma16f(xh[c].x, w4[wofs + c].x, a0);  a1 = mfma16f(xh[c + 1].x, w4[wofs + c + 1].x, a1);             \
+      a0 = mfma16f(xh[c].y, w4[wofs + c].y, a0);  a1 = mfma16f(xh[c + 1].y, w4[wofs + c + 1].y, a1);             \
+      a0 = mfma16f(xh[c].z, w4[wofs + c].z, a0);  a1 = mfma16f(xh[c + 1].z, w4[wofs + c + 1].z, a1);             \
+      a0 = mfma16f(xh[c].w, w4[wofs + c].w, a0);  a1 = mfma16f(xh[c + 1].w, w4[wofs + c + 1].w, a1);             \
+      if (LN) {                                                                                                \
+        sx += ((xh[c].x + xh[c].y) + (xh[c].z + xh[c].w)) + ((xh[c + 1].x + xh[c + 1].y) + (xh[c + 1].z + xh[c + 1].w)); \
+        sq += ((xh[c].x * xh[c].x + xh[c].y * xh[c].y) + (xh[c].z * xh[c].z + xh[c].w * xh[c].w)) +              \
+              ((xh[c + 1].x * xh[c + 1].x + xh[c + 1].y * xh[c + 1].y) + (xh[c + 1].z * xh[c + 1].z + xh[c + 1].w * xh[c + 1].w)); \
+      }                                                                                                        \
     }
+    PIO_HALF(xa, 0)
+    PIO_HALF(xb, HC)
+#undef PIO_HALF
     acc[g] = a0 + a1;
     if (LN) {   // row statistics of x: this lane holds 4*CPW values of row 16g+li; sum the 4 kq groups
       sx += __shfl_xor(sx, 16); sx += __shfl_xor(sx, 32);
