@@ -491,7 +491,8 @@ class Patchioner(nn.Module):
         each on its own stream, can keep several batches in flight (the decode of one batch is a chain of small
         latency-bound kernels that leaves most CUs idle, so it overlaps with the next batch's ViT)."""
         for k in ("bboxes", "get_attn_heads_capt", "get_patch_capts", "get_register_capts"):
-            if kwargs.get(k) not in (None, False):
+            v = kwargs.get(k)
+            if v is not None and v is not False:
                 if not (k == "bboxes" and kwargs.get("get_controllable_capts")):
                     raise NotImplementedError("forward_async supports the flat caption outputs only (%s given)" % k)
         stream = stream or torch.cuda.current_stream()

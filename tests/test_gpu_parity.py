@@ -373,3 +373,26 @@ def test_api_surface_and_mutation_quirks():
     assert torch.equal(boxes, b0 // 14)                                          # floor-divided in place
     with pytest.raises(ValueError):
         m(torch.zeros(1, 3, 196, 196).cuda())
+
+
+def test_forward_async_matches_forward_and_overlaps_instances():
+    """forward_async().result() == forward() for the flat outputs, also with two model instances driving two
+    streams at once (the pipelined mode bench.py uses); unsupported nested outputs fail loudly."""
+    m1, m2 = _make_model(True), _make_model(True)
+    c = gc.E2E
+    imgs = W.synth_images(c["seed_img"], c["B"], c["crop"]).cuda()
+    traces = gc.e2e_traces()
+    kw = dict(get_cls_capt=True, get_avg_self_attn_capt=True, traces=traces, use_attention_tracing=True)
+    want = m1(imgs.clone(), **kw)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    pend = []
+    for i in range(6):
+        m, s = (m1, s1) if i % 2 == 0 else (m2, s2)
+        if len(pend) == 2:
+            assert pend.pop(0).result() == want
+        pend.append(m.forward_async(imgs.clone(), stream=s, **kw))
+    for h in pend:
+        got = h.result()
+        assert got == want and set(got) == {"cls_capt", "avg_self_attn_capt", "trace_capts"}
+    with pytest.raises(NotImplementedError):
+        m1.forward_async(imgs, bboxes=gc.e2e_boxes())
