@@ -1,0 +1,119 @@
+"""GPU parity at the shapes of BASELINE.json's other configurations (reduced depth / batch so that the CPU
+oracle finishes in seconds): config 3 (518^2, 37x37 grid, 16 boxes per image), config 4 (CapDec head = no
+memory bank, many boxes per image, chunked decode), config 5's backbone (ViT-L/14, D = 1024, 16 heads)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from patchioner_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import patchioner_oracle
+    return patchioner_oracle
+
+
+def _model(crop, with_bank, depth=2, dino="dinov2_vitb14_reg", max_batch=4, **over):
+    from patchioner_amd import Patchioner
+    cfg = {"decap_weights": W.synth_decap(3), "prefix_size": 768, "linear_talk2dino": False,
+           "support_memory_size": 2048 if with_bank else 0, "dino_model": dino, "normalize": True,
+           "resize_dim": crop, "crop_dim": crop, "dino_weights": W.synth_dinov2(91, dino, depth=depth),
+           "memory_bank": W.synth_bank(61, 2048) if with_bank else None, "max_batch": max_batch}
+    cfg.update(over)
+    return Patchioner.from_config(cfg, device="cuda")
+
+
+def _oracle_for(O, crop, with_bank, depth=2):
+    from patchioner_amd.tokenizer import ClipDetokenizer
+    vit = O.DinoV2Oracle(W.synth_dinov2(91, depth=depth), num_heads=12)
+    dec = O.DeCapOracle(W.synth_decap(3))
+    bank = W.synth_bank(61, 2048) if with_bank else None
+    return O.PatchionerOracle(vit, dec, bank, ClipDetokenizer().decode, crop_dim=crop)
+
+
+def test_config3_518_boxes_16_regions(O):
+    """talk2dino_decap at 518^2 (T = 1374), 16 gaussian-weighted boxes per image: box features against the
+    oracle on the GPU's own tokens (fp32 tolerance) and the captions of the whole path against the oracle
+    (>= 90 % identical: the backbone is fp16)."""
+    B, NB, crop = 2, 16, 518
+    m = _model(crop, True, max_batch=2)
+    orc = _oracle_for(O, crop, True)
+    imgs = W.synth_images(5, B, crop)
+    rng = np.random.RandomState(4)
+    xy = rng.randint(0, 30, size=(B, NB, 2)) * 14.0
+    wh = rng.randint(1, 8, size=(B, NB, 2)) * 14.0 + rng.randint(0, 14, size=(B, NB, 2))
+    boxes = torch.tensor(np.concatenate([xy, wh], -1), dtype=torch.float32)
+
+    tokens, _ = m.engine.vit_forward(imgs)
+    feats = m._bbox_feats(tokens, boxes.clone(), True, 1.0, False, None)
+    ref = O.extract_bboxes_feats(tokens[:, 5:].cpu(), boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=1.0)
+    np.testing.assert_allclose(feats.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-6)
+
+    got = m(imgs.cuda(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=1.0)
+    want = orc.forward(imgs.clone(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=1.0)
+    assert len(got["bbox_capts"]) == B and all(len(r) == NB for r in got["bbox_capts"])
+    flat_g, flat_w = sum(got["bbox_capts"], []), sum(want["bbox_capts"], [])
+    same = sum(a == b for a, b in zip(flat_g, flat_w))
+    print("config3: %d / %d box captions identical to the oracle" % (same, len(flat_w)))
+    assert same >= 0.9 * len(flat_w)
+
+
+def test_config4_capdec_dense_boxes_chunked(O):
+    """talk2dino_capdec (support_memory_size 0: raw, un-normalised features go to the decoder), 6 images x 24
+    boxes = 144 prefixes: caption chunks of bs*bs_factor = 24 and the engine's 64-prefix decode chunks."""
+    B, NB, crop = 6, 24, 224
+    m = _model(crop, False, max_batch=8)
+    orc = _oracle_for(O, crop, False)
+    imgs = W.synth_images(6, B, crop)
+    rng = np.random.RandomState(8)
+    xy = rng.randint(0, 12, size=(B, NB, 2)) * 14.0
+    wh = rng.randint(1, 8, size=(B, NB, 2)) * 14.0
+    b = np.concatenate([xy, wh], -1).astype(np.float32)
+    b[:, -3:] = [0.0, 0.0, 1.0, 1.0]                       # padding boxes of the dense-captioning driver
+    boxes = torch.tensor(b)
+    got = m(imgs.cuda(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=0.5)
+    want = orc.forward(imgs.clone(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=0.5)
+    flat_g, flat_w = sum(got["bbox_capts"], []), sum(want["bbox_capts"], [])
+    assert len(flat_g) == B * NB
+    same = sum(a == c for a, c in zip(flat_g, flat_w))
+    print("config4: %d / %d box captions identical to the oracle" % (same, len(flat_w)))
+    assert same >= 0.9 * len(flat_w)
+    # decoder stage alone on identical prefixes: bit-exact ids for all 144 prefixes
+    tokens, _ = m.engine.vit_forward(imgs)
+    feats = m._bbox_feats(tokens, boxes.clone(), True, 0.5, False, None).view(-1, 768)
+    ids, _ = m.engine.decode_greedy(feats)
+    ref_ids, _, margin = O.DeCapOracle(W.synth_decap(3)).decode_ids(feats.cpu())
+    assert np.array_equal(ids.cpu().numpy(), ref_ids.numpy()), "min margin %.2e" % float(margin.min())
+
+
+def test_config5_backbone_vitl14(O):
+    """ViT-L/14-reg geometry (D = 1024, 16 heads; depth 2 of 24) in fp16: tokens and the qkv capture vs the oracle."""
+    from patchioner_amd.engine import Engine
+    sd = W.synth_dinov2(23, "dinov2_vitl14_reg", depth=2)
+    e = Engine(embed_dim=1024, depth=2, num_heads=16, num_registers=4, crop_dim=224, max_batch=4, vit_dtype="fp16")
+    try:
+        e.load_state_dict(sd)
+        e.finalize()
+        imgs = W.synth_images(29, 3, 224)
+        tokens, qkv = e.vit_forward(imgs)
+        vit = O.DinoV2Oracle(sd, num_heads=16)
+        d = vit(imgs)
+        ref = torch.cat([d["x_norm_clstoken"][:, None], d["x_norm_regtokens"], d["x_norm_patchtokens"]], 1)
+        err = (tokens.cpu() - ref).abs().max() / ref.abs().max()
+        qerr = (qkv.cpu() - vit.last_qkv).abs().max() / vit.last_qkv.abs().max()
+        print("vit-L rel-max-err %.2e, qkv %.2e" % (err, qerr))
+        assert err <= 4e-3 and qerr <= 4e-3
+        # read-out on the 1024-wide capture: 16 heads x 64 channels
+        sa, maps, avg, dis = e.cls_attention(qkv, tokens, want_maps=True, want_avg=True, want_disentangled=True)
+        rsa, rmaps = O.process_self_attention(qkv.cpu(), 3, 261, 16, 1024, 0.125, 5)
+        ravg, rdis = O.attention_weighted_means(rsa, rmaps, tokens[:, 5:].cpu())
+        np.testing.assert_allclose(sa.cpu().numpy(), rsa.numpy(), rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(avg.cpu().numpy(), ravg.numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(dis.cpu().numpy(), rdis.numpy(), rtol=1e-4, atol=1e-6)
+    finally:
+        e.close()

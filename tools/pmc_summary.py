@@ -1,0 +1,53 @@
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into HBM bytes per launch per kernel.
+
+    python tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> [out.json]
+
+gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts a 128-B request as 64 B for wide coalesced
+streaming reads (16 B per lane), so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.  Both counters
+are in KiB.  Launches of the benchmark's warm-up / timed / profiled regions are averaged together.
+"""
+import collections
+import csv
+import json
+import sys
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            name = r["Kernel_Name"]
+            key = name.split("(")[0].replace("void ", "")[:80]
+            acc[key][0] += 1
+            acc[key][1] += float(r["Counter_Value"])
+    return acc
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        if "pio" not in k:
+            continue
+        nf, f = fetch.get(k, [0, 0.0])
+        nw, w = write.get(k, [0, 0.0])
+        n = max(nf, nw, 1)
+        out[k] = {"launches": n, "fetch_kib_raw_per_launch": f / max(nf, 1), "write_kib_per_launch": w / max(nw, 1),
+                  "hbm_bytes_per_launch": (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0}
+    gemm = [v for k, v in out.items() if "k_vit_gemm" in k]
+    tot_l = sum(v["launches"] for v in gemm)
+    summary = {"kernels": out,
+               "vit_gemm_hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches"] for v in gemm) / max(tot_l, 1)}
+    text = json.dumps(summary, indent=1)
+    if len(sys.argv) > 3:
+        open(sys.argv[3], "w").write(text)
+    for k, v in out.items():
+        print("%-70s n=%5d  HBM %.2f MB/launch" % (k, v["launches"], v["hbm_bytes_per_launch"] / 1e6))
+    print("vit_gemm average: %.2f MB/launch" % (summary["vit_gemm_hbm_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
