@@ -93,6 +93,7 @@ def main():
                     help="batches kept in flight per GPU (each on its own model instance and stream; the decode of "
                          "one batch is latency-bound and overlaps with the next batch's ViT); 1 = the reference's "
                          "synchronous forward, which is also always measured and reported as `sync`")
+    ap.add_argument("--mode", choices=["group", "streams"], default=os.environ.get("PIO_BENCH_MODE", "group"))
     args = ap.parse_args()
 
     from patchioner_amd import dist as pdist
@@ -104,7 +105,7 @@ def main():
     import torch.distributed as dist
 
     P = max(1, args.in_flight)
-    models = build_models(local, P)
+    models = build_models(local, P if args.mode == "streams" else 1)
     model = models[0]
     streams = [torch.cuda.Stream() for _ in range(P)]
     imgs, traces = make_inputs()
@@ -114,12 +115,24 @@ def main():
         ids = pdist.all_gather_equal_ids(model.last_ids)       # the path's only exchange: final captions' ids
         return outs, ids
 
+    pipe = None
+    if args.mode == "group" and P > 1:
+        from patchioner_amd.pipeline import TraceCaptionPipeline
+        pipe = TraceCaptionPipeline(model, group_batches=P)
+
     def run_steps(n):
-        """n forwards; with P > 1, P of them are in flight (model instance i % P on stream i % P)"""
+        """n forwards.  mode=group: stage 1 (ViT .. projection) per batch, ONE decode per P batches, the two stages
+        overlapped on two streams (pipeline.py).  mode=streams: P whole forwards in flight, model instance i % P on
+        stream i % P."""
         if P == 1:
             for _ in range(n):
                 outs, ids = step()
             return outs, ids
+        if pipe is not None:
+            caps = None
+            for caps in pipe.run((imgs, traces) for _ in range(n)):
+                pass
+            return {"trace_capts": caps}, pdist.all_gather_equal_ids(pipe.last_ids[-BATCH:])
         from collections import deque
         pend = deque()
         outs = ids = None
@@ -193,7 +206,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
             "config": {"workload": "talk2dino_decap_COCO, ViT-B/14-reg 224^2, batch 16/GPU, caption_from=patches "
                                    "(one 16-patch trace region per image), bank 591753x768 fp32, 30-step greedy decode",
-                       "global_batch": BATCH * world, "parallelism": "dp%d (image shards, ids all-gather)" % world, "batches_in_flight_per_gpu": P},
+                       "global_batch": BATCH * world, "parallelism": "dp%d (image shards, ids all-gather)" % world, "batches_in_flight_per_gpu": P,
+                       "pipelining": "none" if P == 1 else ("one decode per %d batches, overlapped with the next batches' ViT" % P
+                                                           if args.mode == "group" else "%d forwards on %d streams" % (P, P))},
             "roofline": {"kernel": "k_vit_gemm (fp16 MFMA 32x32x16, 60+1 launches/step)", "bound": "mfma",
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,

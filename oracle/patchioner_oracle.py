@@ -407,7 +407,8 @@ class PatchionerOracle:
             return caps, torch.exp(lps.sum(-1)).tolist()
         return caps
 
-    def forward(self, imgs, get_cls_capt=True, get_avg_self_attn_capt=False, bboxes=None, traces=None,
+    def forward(self, imgs, get_cls_capt=True, get_avg_self_attn_capt=False, get_attn_heads_capt=False,
+                get_patch_capts=False, get_register_capts=False, bboxes=None, traces=None,
                 get_controllable_capts=False, bs_factor=4, gaussian_avg=False, gaussian_bbox_variance=0.5,
                 get_avg_patch_capt=False, gaussian_img_variance=1, use_attn_map_for_bboxes=False,
                 use_attention_tracing=False, compute_scores=False):
@@ -417,7 +418,7 @@ class PatchionerOracle:
         patches = d["x_norm_patchtokens"]
         self_attn, maps = process_self_attention(self.vit.last_qkv, bs, self.num_tokens, self.num_attn_heads,
                                                  self.embed_dim, self.scale, self.num_global_tokens)
-        avg_tok, _ = attention_weighted_means(self_attn, maps, patches)
+        avg_tok, disentangled = attention_weighted_means(self_attn, maps, patches)
         D = patches.shape[-1]
 
         def put(key, ret):
@@ -433,6 +434,20 @@ class PatchionerOracle:
         if get_avg_patch_capt:
             put("avg_patch_capt", self.caption_tokens(compute_region_means(patches, gaussian_img_variance),
                                                       compute_scores=compute_scores))
+        # P/src/model.py:946-975: nested per-image lists of 16 head / n*n patch / 4 register captions
+        def nested(key, score_key, toks, per):
+            ret = self.caption_tokens(toks, compute_scores=compute_scores)
+            caps = ret[0] if compute_scores else ret
+            outs[key] = [caps[i * per:(i + 1) * per] for i in range(bs)]
+            if compute_scores:
+                outs[score_key] = [ret[1][i * per:(i + 1) * per] for i in range(bs)]
+
+        if get_attn_heads_capt:
+            nested("attn_heads_capts", "attn_heads_scores", disentangled.reshape(-1, D), self.num_attn_heads)
+        if get_patch_capts:
+            nested("patch_tokens_capts", "patch_tokens_scores", patches.reshape(-1, D), patches.shape[1])
+        if get_register_capts:
+            nested("register_capts", "register_scores", d["x_norm_regtokens"].reshape(-1, D), 4)
         if bboxes is not None and not get_controllable_capts:
             n_boxes = bboxes.shape[1]
             amap = self_attn if use_attn_map_for_bboxes else None

@@ -107,7 +107,7 @@ struct pio_context {
   // memory bank
   float* bank = nullptr; float* bank_inv = nullptr; int64_t bank_rows = 0; int bank_dim = 0;
   float *part_acc = nullptr, *part_ml = nullptr, *sims = nullptr;
-  int parts = 256;
+  int parts = 512;   // two k_project workgroups per CU
   // live HIP-event profiling (pio_profile_*): one (start, stop) pair per bracketed launch
   struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };
   bool prof_on = false;

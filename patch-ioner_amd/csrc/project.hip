@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_row_inv_norm(const float* __restrict__ 
 }
 
 template <int D>
-__global__ __launch_bounds__(256, 1) void k_project(const float* __restrict__ bank, const float* __restrict__ inv_norm,
+__global__ __launch_bounds__(256, 2) void k_project(const float* __restrict__ bank, const float* __restrict__ inv_norm,
                                                     int64_t M, const float* __restrict__ q, int N, int q0,
                                                     float temperature, float* part_acc, float* part_ml, int parts) {
   constexpr int STRIDE = D + 4;                  // floats; +16 B skews rows across the 64 banks
@@ -65,9 +65,8 @@ __global__ __launch_bounds__(256, 1) void k_project(const float* __restrict__ ba
   constexpr int NV = D / 4 * PR_ROWS / 256;      // float4 per thread per tile
   static_assert(D % 64 == 0 && (D / 4 * PR_ROWS) % 256 == 0, "D");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* s_bank = lds;                            // [2][16][STRIDE]
-  float* s_q = lds + 2 * PR_ROWS * STRIDE;        // [16][STRIDE]
-  float* s_red = s_q + PR_Q * STRIDE;             // [4][256]
+  float* s_bank = lds;                            // [16][STRIDE]  (single buffer: two workgroups share a CU)
+  float* s_red = lds + PR_ROWS * STRIDE;          // [4][256]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
 
@@ -78,12 +77,13 @@ __global__ __launch_bounds__(256, 1) void k_project(const float* __restrict__ ba
   int64_t t_end = t_begin + tiles_per;
   if (t_end > tiles_total) t_end = tiles_total;
 
-  // queries -> LDS (zero rows for n >= N)
-  for (int i = tid; i < PR_Q * (D / 4); i += 256) {
-    const int n = i / (D / 4), c = i - n * (D / 4);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q0 + n < N) v = ((const float4*)(q + (size_t)(q0 + n) * D))[c];
-    *(float4*)(s_q + n * STRIDE + 4 * c) = v;
+  // this wave's slice of the 16 queries stays in registers for the whole slab (zero rows for n >= N):
+  // lane (li = query, kq) holds q[q0+li][wid*DW + 16c + 4kq .. +3]
+  float4 qreg[DW / 16];
+#pragma unroll
+  for (int c = 0; c < DW / 16; ++c) {
+    qreg[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q0 + li < N) qreg[c] = *(const float4*)(q + (size_t)(q0 + li) * D + wid * DW + 16 * c + 4 * kq);
   }
 
   // Per-thread staging of the next tile: NV <= 12 float4 held in NAMED registers (hipcc keeps a staged
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256, 1) void k_project(const float* __restrict__ ba
 #define PIO_BANK_SRC(t, i) \
   (((const float4*)(bank + (((t) * PR_ROWS + (tid + 256 * (i)) / (D / 4)) < M ? ((t) * PR_ROWS + (tid + 256 * (i)) / (D / 4)) : M - 1) * D))[(tid + 256 * (i)) % (D / 4)])
 #define PIO_BANK_DST(buf, i) \
-  (*(float4*)(s_bank + ((buf) * PR_ROWS + (tid + 256 * (i)) / (D / 4)) * STRIDE + 4 * ((tid + 256 * (i)) % (D / 4))))
+  (*(float4*)(s_bank + ((tid + 256 * (i)) / (D / 4)) * STRIDE + 4 * ((tid + 256 * (i)) % (D / 4))))
 #define PIO_LOAD_BANK(t)                                  \
   do {                                                    \
     if constexpr (NV > 0) g0 = PIO_BANK_SRC(t, 0);        \
@@ -136,17 +136,16 @@ __global__ __launch_bounds__(256, 1) void k_project(const float* __restrict__ ba
   }
   __syncthreads();
   for (int64_t t = t_begin; t < t_end; ++t) {
-    const int buf = (int)((t - t_begin) & 1);
-    const int64_t tn = t + 1 < t_end ? t + 1 : t;   // last iteration: reload own tile, stored into the dead buffer
+    const int64_t tn = t + 1 < t_end ? t + 1 : t;   // last iteration: reloads its own tile (stored, never read)
     PIO_LOAD_BANK(tn)
-    const float* sb = s_bank + buf * PR_ROWS * STRIDE;
+    const float* sb = s_bank;
     // ---- GEMM1: partial S[row][n] over this wave's channels ----
     f32x4 sp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < DW / 16; ++c) {
       const int d = wid * DW + 16 * c + 4 * kq;
       const float4 a = *(const float4*)(sb + li * STRIDE + d);
-      const float4 b = *(const float4*)(s_q + li * STRIDE + d);
+      const float4 b = qreg[c];
       sp = mfma16(a.x, b.x, sp);
       sp = mfma16(a.y, b.y, sp);
       sp = mfma16(a.z, b.z, sp);
@@ -200,7 +199,8 @@ __global__ __launch_bounds__(256, 1) void k_project(const float* __restrict__ ba
       for (int tt = 0; tt < 4; ++tt) a4 = mfma16(p[tt], bp[tt * STRIDE], a4);
       acc[j] = a4;
     }
-    PIO_STORE_BANK(buf ^ 1)
+    __syncthreads();                 // every wave is done reading this tile
+    PIO_STORE_BANK(0)
     __syncthreads();
   }
 #undef PIO_LOAD_BANK
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_revert(const float* __restrict__ x, con
 
 template <int D>
 static hipError_t project_pass(const ProjectArgs& a, int q0, hipStream_t s) {
-  const int smem = (2 * PR_ROWS * (D + 4) + PR_Q * (D + 4) + 4 * 256) * (int)sizeof(float);
+  const int smem = (PR_ROWS * (D + 4) + 4 * 256) * (int)sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_project<D>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);

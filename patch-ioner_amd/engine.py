@@ -51,8 +51,8 @@ class Engine:
         self.num_weights = 0
         self.bank_rows = 0
         self._finalized = False
-        self._stage_host = None
-        self._stage_dev = None
+        self._stage_ring = [dict(host=None, dev=None, event=None) for _ in range(8)]
+        self._stage_next = 0
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
@@ -152,24 +152,32 @@ class Engine:
     def trace_grids(self, traces: Sequence[Sequence[dict]]) -> torch.Tensor:
         """map_traces_to_grid for a batch: points packed CSR-style into ONE pinned staging buffer (x, y as
         float64 followed by the int32 offsets) and sent with one asynchronous copy; the counting runs on
-        the device."""
+        the device.  A ring of 8 staging slots (each guarded by an event) lets the host run several batches
+        ahead of the GPU without overwriting a buffer whose copy has not executed yet."""
         B = len(traces)
         xy = np.array([(p["x"], p["y"]) for tr in traces for p in tr], dtype=np.float64).reshape(-1, 2)
         npts = xy.shape[0]
         nbytes = npts * 16 + (B + 1) * 4
-        if self._stage_host is None or self._stage_host.numel() < nbytes:
+        slot = self._stage_ring[self._stage_next % len(self._stage_ring)]
+        self._stage_next += 1
+        if slot["event"] is not None:
+            slot["event"].synchronize()
+        if slot["host"] is None or slot["host"].numel() < nbytes:
             cap = max(1 << 16, 2 * nbytes)
-            self._stage_host = torch.empty(cap, dtype=torch.uint8).pin_memory()
-            self._stage_dev = torch.empty(cap, dtype=torch.uint8, device=self.device)
-        host = self._stage_host.numpy()
+            slot["host"] = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            slot["dev"] = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        host = slot["host"].numpy()
         host[: npts * 16].view(np.float64)[:] = xy.reshape(-1)
         offs = host[npts * 16: nbytes].view(np.int32)
         offs[0] = 0
         np.cumsum([len(tr) for tr in traces], out=offs[1:])
-        self._stage_dev[:nbytes].copy_(self._stage_host[:nbytes], non_blocking=True)
-        base = self._stage_dev.data_ptr()
+        slot["dev"][:nbytes].copy_(slot["host"][:nbytes], non_blocking=True)
+        base = slot["dev"].data_ptr()
         grids = torch.empty(B, self.n, self.n, device=self.device, dtype=torch.float32)
         check(self.lib.pio_trace_grids(self.h, base if npts else None, base + npts * 16, B, npts, ptr(grids), _stream()))
+        if slot["event"] is None:
+            slot["event"] = torch.cuda.Event()
+        slot["event"].record(torch.cuda.current_stream())
         return grids
 
     # ------------------------------------------------------------------ a7 boxes

@@ -117,3 +117,45 @@ def test_config5_backbone_vitl14(O):
         np.testing.assert_allclose(dis.cpu().numpy(), rdis.numpy(), rtol=1e-4, atol=1e-6)
     finally:
         e.close()
+
+
+def test_nested_caption_outputs_heads_patches_registers(O):
+    """get_attn_heads_capt / get_patch_capts / get_register_capts (P/src/model.py:938-975): 16 + 256 + 4
+    captions per image (the largest decode batches of the path), nesting and captions vs the oracle."""
+    B, crop = 1, 224
+    m = _model(crop, True, max_batch=2)
+    orc = _oracle_for(O, crop, True)
+    imgs = W.synth_images(12, B, crop)
+    kw = dict(get_cls_capt=False, get_attn_heads_capt=True, get_patch_capts=True, get_register_capts=True)
+    got = m(imgs.cuda(), **kw)
+    want = orc.forward(imgs.clone(), **kw)
+    assert set(got) == set(want) == {"attn_heads_capts", "patch_tokens_capts", "register_capts"}
+    total = same = 0
+    for key, per in (("attn_heads_capts", 16), ("patch_tokens_capts", 256), ("register_capts", 4)):
+        assert len(got[key]) == B and all(len(r) == per for r in got[key])
+        for a, b in zip(sum(got[key], []), sum(want[key], [])):
+            total += 1
+            same += a == b
+    print("nested outputs: %d / %d captions identical to the oracle" % (same, total))
+    assert same >= 0.9 * total
+
+
+def test_grouped_decode_pipeline_matches_synchronous_forward():
+    """pipeline.TraceCaptionPipeline (stage 1 per batch, one decode per group of batches, two streams) returns
+    exactly the captions of the synchronous forward, batch by batch and in order; ragged batches, a partial
+    last group, attention-weighted traces and the cls path included."""
+    from patchioner_amd.pipeline import TraceCaptionPipeline
+    m = _model(224, True, max_batch=8)
+    rng = np.random.RandomState(3)
+    batches = []
+    for i, b in enumerate([4, 8, 3, 8, 8, 5, 2]):
+        imgs = W.synth_images(100 + i, b, 224).cuda()
+        traces = [gc.block_trace(int(rng.randint(0, 13)), int(rng.randint(0, 13))) for _ in range(b)]
+        batches.append((imgs, traces))
+    for attn in (False, True):
+        want = [m(imgs, get_cls_capt=False, traces=tr, use_attention_tracing=attn)["trace_capts"] for imgs, tr in batches]
+        got = list(TraceCaptionPipeline(m, group_batches=3, use_attention_tracing=attn).run(batches))
+        assert got == want
+    want = [m(imgs, get_cls_capt=True)["cls_capt"] for imgs, _ in batches]
+    got = list(TraceCaptionPipeline(m, group_batches=4).run((imgs, None) for imgs, _ in batches))
+    assert got == want
