@@ -94,6 +94,8 @@ def main():
                          "one batch is latency-bound and overlaps with the next batch's ViT); 1 = the reference's "
                          "synchronous forward, which is also always measured and reported as `sync`")
     ap.add_argument("--mode", choices=["group", "streams"], default=os.environ.get("PIO_BENCH_MODE", "group"))
+    ap.add_argument("--stage-streams", type=int, default=int(os.environ.get("PIO_BENCH_STAGE_STREAMS", "1")),
+                    help="mode=group: model replicas (own ViT workspace, own stream) that stage 1 alternates over")
     args = ap.parse_args()
 
     from patchioner_amd import dist as pdist
@@ -105,7 +107,8 @@ def main():
     import torch.distributed as dist
 
     P = max(1, args.in_flight)
-    models = build_models(local, P if args.mode == "streams" else 1)
+    S = max(1, args.stage_streams)
+    models = build_models(local, P if args.mode == "streams" else S)
     model = models[0]
     streams = [torch.cuda.Stream() for _ in range(P)]
     imgs, traces = make_inputs()
@@ -118,7 +121,8 @@ def main():
     pipe = None
     if args.mode == "group" and P > 1:
         from patchioner_amd.pipeline import TraceCaptionPipeline
-        pipe = TraceCaptionPipeline(model, group_batches=P)
+        pipe = TraceCaptionPipeline(model, group_batches=P, stage_replicas=models[1:S],
+                                    stage_cus=int(os.environ.get("PIO_STAGE_CUS", "0")) or None)
 
     def run_steps(n):
         """n forwards.  mode=group: stage 1 (ViT .. projection) per batch, ONE decode per P batches, the two stages
@@ -207,7 +211,7 @@ def main():
             "config": {"workload": "talk2dino_decap_COCO, ViT-B/14-reg 224^2, batch 16/GPU, caption_from=patches "
                                    "(one 16-patch trace region per image), bank 591753x768 fp32, 30-step greedy decode",
                        "global_batch": BATCH * world, "parallelism": "dp%d (image shards, ids all-gather)" % world, "batches_in_flight_per_gpu": P,
-                       "pipelining": "none" if P == 1 else ("one decode per %d batches, overlapped with the next batches' ViT" % P
+                       "pipelining": "none" if P == 1 else ("one decode per %d batches, overlapped with the next batches' ViT on %d stream(s)" % (P, S)
                                                            if args.mode == "group" else "%d forwards on %d streams" % (P, P))},
             "roofline": {"kernel": "k_vit_gemm (fp16 MFMA 32x32x16, 60+1 launches/step)", "bound": "mfma",
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

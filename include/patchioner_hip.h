@@ -76,6 +76,13 @@ typedef struct {
 const char* pio_last_error(void);
 const char* pio_version(void);
 
+/* -- stream plumbing for pipeline.py (no reference counterpart: the reference runs on torch's current stream).
+ *    A HIP stream restricted to the first `n_cus` compute units of `device` (hipExtStreamCreateWithCUMask), so that
+ *    a latency-bound stage (the greedy decode) keeps compute units of its own beside the ViT GEMMs of the next
+ *    batches.  n_cus <= 0 or >= the device's CU count: an ordinary stream.  `skip_cus` shifts the window. -- */
+int pio_stream_create(int32_t device, int32_t skip_cus, int32_t n_cus, void** stream);
+int pio_stream_destroy(void* stream);
+
 /* -- a1: construction (replaces Patchioner.__init__ / from_config, P/src/model.py:98-662, 666-715) -- */
 int pio_create(const pio_config* cfg, pio_handle* out);
 int pio_destroy(pio_handle h);

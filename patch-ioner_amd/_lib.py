@@ -41,6 +41,8 @@ class PioConfig(ctypes.Structure):
 SIGNATURES = {
     "pio_last_error": (c_char_p, []),
     "pio_version": (c_char_p, []),
+    "pio_stream_create": (c_int32, [c_int32, c_int32, c_int32, POINTER(c_void_p)]),
+    "pio_stream_destroy": (c_int32, [c_void_p]),
     "pio_create": (c_int32, [POINTER(PioConfig), POINTER(c_void_p)]),
     "pio_destroy": (c_int32, [c_void_p]),
     "pio_load_weight": (c_int32, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int32]),

@@ -372,6 +372,30 @@ extern "C" {
 const char* pio_last_error(void) { return g_err.c_str(); }
 const char* pio_version(void) { return "patchioner_hip 0.1.0 (gfx950)"; }
 
+int pio_stream_create(int32_t device, int32_t skip_cus, int32_t n_cus, void** stream) {
+  if (!stream || skip_cus < 0) return fail(PIO_ERR_INVALID_ARG, "pio_stream_create: bad argument");
+  HIP_OK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, device));
+  const int total = prop.multiProcessorCount;
+  hipStream_t s = nullptr;
+  if (n_cus <= 0 || (skip_cus == 0 && n_cus >= total)) {
+    HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  } else {
+    if (skip_cus + n_cus > total) return fail(PIO_ERR_INVALID_ARG, "pio_stream_create: CU window exceeds the device");
+    std::vector<uint32_t> mask((total + 31) / 32, 0u);
+    for (int i = skip_cus; i < skip_cus + n_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+    HIP_OK(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+  }
+  *stream = (void*)s;
+  return PIO_OK;
+}
+
+int pio_stream_destroy(void* stream) {
+  if (stream) HIP_OK(hipStreamDestroy((hipStream_t)stream));
+  return PIO_OK;
+}
+
 int pio_create(const pio_config* cfg, pio_handle* out) {
   if (!cfg || !out) return fail(PIO_ERR_INVALID_ARG, "pio_create: null argument");
   if (cfg->embed_dim % 64 != 0 || cfg->embed_dim / 64 != cfg->num_heads)

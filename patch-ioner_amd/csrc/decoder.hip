@@ -41,6 +41,9 @@ namespace pio {
 #ifndef PIO_DEC_GEMM_WAVES
 #define PIO_DEC_GEMM_WAVES 2
 #endif
+#ifndef PIO_LMHEAD_WIDE
+#define PIO_LMHEAD_WIDE 1
+#endif
 #ifndef PIO_LMHEAD_CG
 #define PIO_LMHEAD_CG 1
 #endif
@@ -386,6 +389,175 @@ hipError_t decoder_init() { return hipSuccess; }   // no function attributes nee
 
 #define PIO_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
 
+// ---- LM head, wide form ------------------------------------------------------------------------------------
+// The generic kernel above re-reads all of X (N x 768 fp32) per 16 columns: 3142 workgroups x up to 196 KB through
+// L2 -> L1 (at 64 prefixes that, not the 154 MB weight stream or the MFMAs, sets the time: 95 us vs 62 us with the X
+// loads compiled out).  Here a workgroup owns 64 columns (wave w: 16 of them, the FULL K), K is walked in 12 chunks
+// of 64 and the X chunk ([16 RG][64] fp32, 16-B slots XOR-swizzled with the row so that the ds_read_b128 A fragments
+// are conflict-free) is staged ONCE per workgroup by LDS-DMA into a double buffer and shared by the four waves: X
+// traffic / 4, no cross-wave reduction.  W streams HBM -> registers, three chunk sets deep (two chunks ahead).
+// Numerics are BIT-IDENTICAL to k_dec_gemm<.., DE_ARGMAX, LN>: the same lane <-> (column, k) mapping, the same two
+// MFMA chains per 192-k slice, slices added in order, LayerNorm row sums built per slice in the same order.
+typedef __attribute__((address_space(3))) void* dec_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* dec_gbl_ptr_t;
+
+template <int RG>
+__global__ __launch_bounds__(256, 2) void k_lmhead_wide(const float* __restrict__ W, const float* __restrict__ X, int N, int V,
+                                                        const float* __restrict__ dvec, const float* __restrict__ cvec,
+                                                        float eps, float* part) {
+  constexpr int K = 768, CH = 64, NCH = K / CH, ROWS = RG * 16, XB = ROWS * CH;
+  extern __shared__ __attribute__((aligned(16))) float lsm[];      // [2][ROWS][64] X chunks | s_sum[4][ROWS] | s_sq[4][ROWS]
+  float* s_sum = lsm + 2 * XB;
+  float* s_sq = s_sum + 4 * ROWS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int blk = blockIdx.x * 4 + wid;            // 16-column group of this wave
+  const int j = blk * 16 + li;
+  const int jc = j < V ? j : V - 1;
+  const float* wp = W + (size_t)jc * K + 4 * kq;
+
+  // LDS-DMA pieces of an X chunk: piece t = wid + 4 i covers rows 4t .. 4t+3 (1 KiB); lane l fills slot (l & 15) of
+  // row 4t + (l >> 4) and therefore fetches source chunk (l & 15) ^ (row & 15).
+  uint32_t xoff[RG];
+#pragma unroll
+  for (int i = 0; i < RG; ++i) {
+    const int row = 4 * (wid + 4 * i) + (lane >> 4);
+    const int rc = row < N ? row : N - 1;
+    xoff[i] = (uint32_t)rc * K + 4 * ((lane & 15) ^ (row & 15));
+  }
+  // (LDS-DMA in inline asm as well: hipcc drains vmcnt(0) before every ds_read that follows a builtin LDS-DMA.
+  //  M0 = wave-uniform LDS byte address of the piece; saved and restored inside the statement.)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(dec_lds_ptr_t)lsm + (uint32_t)wid * 1024u;
+#define PIO_XISSUE(q, buf)                                                                                     \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < RG; ++i) {                                                           \
+      const float* _g = X + (q) * CH + xoff[i];                                                                \
+      const uint32_t _l = lds0 + (uint32_t)((buf) * XB * 4 + i * 4096);                                        \
+      uint32_t _keep;                                                                                          \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                   : "=&s"(_keep) : "v"(_g), "s"(_l) : "memory");                                              \
+    }                                                                                                          \
+  } while (0)
+  // The weight loads are inline asm: beside an LDS-DMA in flight hipcc waits vmcnt(0) before the first use of ANY
+  // ordinary load result, which would drain the two-chunk prefetch every chunk.  hipcc does not count asm loads, so
+  // the vm queue is counted by hand (PIO_WWAIT names the destinations "+v": no consumer is scheduled above it).
+  // Queue order per chunk: W(q) | X(q) | W(q+1): with <= 4 outstanding, W(q) and X(q) have landed.
+#define PIO_WLOAD(set, q)                                                                                      \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                            \
+      const float* _p = wp + (q) * CH + 16 * c;                                                                \
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[set][c]) : "v"(_p) : "memory");                  \
+    }                                                                                                          \
+  } while (0)
+#define PIO_WWAIT(set, cnt)                                                                                    \
+  asm volatile("s_waitcnt vmcnt(" #cnt ")" : "+v"(w[set][0]), "+v"(w[set][1]), "+v"(w[set][2]), "+v"(w[set][3]) :: "memory")
+
+  f32x4 w[3][4];
+  f32x4 tot[RG], a0[RG], a1[RG];
+  float sx[RG], sq[RG];
+  PIO_WLOAD(0, 0);
+  PIO_XISSUE(0, 0);
+  PIO_WLOAD(1, 1);
+  // Fully unrolled on purpose: with a runtime loop hipcc rotates the weight sets through v_mov copies at the back
+  // edge, i.e. it copies registers whose asm loads have not landed yet (audit: tools/microbench/asm_load_audit.py).
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {                 // 192-k slices
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      a0[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; a1[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      sx[g] = 0.f; sq[g] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {                  // chunk q = 3 sl + r uses weight set r
+      const int q = 3 * sl + r;
+      // W(q) and X chunk q have landed once at most the 4 weight loads issued after them are outstanding
+      if (q + 1 < NCH) PIO_WWAIT(r, 4);
+      else PIO_WWAIT(r, 0);
+      __builtin_amdgcn_s_barrier();                // ... in every wave; and every wave is done with buffer (q+1)&1
+      if (q + 1 < NCH) PIO_XISSUE(q + 1, (q + 1) & 1);
+      if (q + 2 < NCH) PIO_WLOAD((r + 2) % 3, q + 2);
+      const float* xb = lsm + (q & 1) * XB;
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        float4 xf[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xf[c] = *(const float4*)(xb + (16 * g + li) * CH + (((4 * c + kq) ^ li) << 2));
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {
+          a0[g] = mfma16f(xf[c].x, w[r][c][0], a0[g]);  a1[g] = mfma16f(xf[c + 1].x, w[r][c + 1][0], a1[g]);
+          a0[g] = mfma16f(xf[c].y, w[r][c][1], a0[g]);  a1[g] = mfma16f(xf[c + 1].y, w[r][c + 1][1], a1[g]);
+          a0[g] = mfma16f(xf[c].z, w[r][c][2], a0[g]);  a1[g] = mfma16f(xf[c + 1].z, w[r][c + 1][2], a1[g]);
+          a0[g] = mfma16f(xf[c].w, w[r][c][3], a0[g]);  a1[g] = mfma16f(xf[c + 1].w, w[r][c + 1][3], a1[g]);
+          if (wid == (g & 3)) {     // the LayerNorm row sums of group g are built by one wave only
+            sx[g] += ((xf[c].x + xf[c].y) + (xf[c].z + xf[c].w)) + ((xf[c + 1].x + xf[c + 1].y) + (xf[c + 1].z + xf[c + 1].w));
+            sq[g] += ((xf[c].x * xf[c].x + xf[c].y * xf[c].y) + (xf[c].z * xf[c].z + xf[c].w * xf[c].w)) +
+                     ((xf[c + 1].x * xf[c + 1].x + xf[c + 1].y * xf[c + 1].y) + (xf[c + 1].z * xf[c + 1].z + xf[c + 1].w * xf[c + 1].w));
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {                 // the slice is complete
+      const f32x4 p = a0[g] + a1[g];
+      tot[g] = sl == 0 ? p : tot[g] + p;
+      if (wid == (g & 3)) {
+        float tx = sx[g], tq = sq[g];
+        tx += __shfl_xor(tx, 16); tx += __shfl_xor(tx, 32);
+        tq += __shfl_xor(tq, 16); tq += __shfl_xor(tq, 32);
+        if (kq == 0) { s_sum[sl * ROWS + g * 16 + li] = tx; s_sq[sl * ROWS + g * 16 + li] = tq; }
+      }
+    }
+  }
+#undef PIO_XISSUE
+#undef PIO_WLOAD
+#undef PIO_WWAIT
+  const float bj = dvec[jc], cj = cvec[jc];
+  __syncthreads();                                 // row sums visible
+  if (blk * 16 >= V) return;                       // wave-uniform: no columns
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {
+    f32x4 sacc = tot[g];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = g * 16 + 4 * kq + i;
+      const float tx = (s_sum[0 * ROWS + rr] + s_sum[1 * ROWS + rr]) + (s_sum[2 * ROWS + rr] + s_sum[3 * ROWS + rr]);
+      const float tq = (s_sq[0 * ROWS + rr] + s_sq[1 * ROWS + rr]) + (s_sq[2 * ROWS + rr] + s_sq[3 * ROWS + rr]);
+      const float mu = tx / (float)K;
+      const float var = fmaxf(tq / (float)K - mu * mu, 0.f);
+      sacc[i] = rsqrtf(var + eps) * (sacc[i] - mu * cj) + bj;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = j < V ? sacc[i] : -INFINITY;
+      int idx = j;
+      float mx = v;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const float ov = __shfl_xor(mx, o);
+        const int oi = __shfl_xor(idx, o);
+        if (ov > mx || (ov == mx && oi < idx)) { mx = ov; idx = oi; }
+      }
+      float se = j < V ? expf(v - mx) : 0.f;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o);
+      const int n = g * 16 + 4 * kq + i;
+      if (li == 0 && n < N) {
+        float* p = part + ((size_t)blk * N + n) * 4;
+        p[0] = mx; p[1] = __int_as_float(idx); p[2] = se;
+      }
+    }
+  }
+}
+
+template <int RG>
+static hipError_t launch_lmhead_wide(const float* W, const float* X, int N, int V, const float* dvec, const float* cvec,
+                                     float eps, float* part, hipStream_t s) {
+  const int smem = (2 * RG * 16 * 64 + 8 * RG * 16) * 4;
+  hipLaunchKernelGGL((k_lmhead_wide<RG>), dim3(ceil_div(V, 64)), dim3(256), smem, s, W, X, N, V, dvec, cvec, eps, part);
+  return hipGetLastError();
+}
+
 // LM head -> greedy partials: one (max, arg-max, sum-exp) per prefix and 16-column group.
 // (A persistent variant that keeps x in registers and walks 5-7 column groups per workgroup measured
 //  50 us against 41 us for this one at 16 prefixes: fewer bytes in flight per CU and a serial per-group
@@ -393,6 +565,12 @@ hipError_t decoder_init() { return hipSuccess; }   // no function attributes nee
 hipError_t launch_lmhead(const float* W, const float* X, int N, int V, int E, const float* dvec, const float* cvec,
                          float eps, float* part, int* nblk, hipStream_t s) {
   *nblk = ceil_div(V, 16);
+  if (PIO_LMHEAD_WIDE && E == 768 && N >= 1 && N <= 64) {
+    const int rg = ceil_div(N, 16);
+    if (rg <= 1) return launch_lmhead_wide<1>(W, X, N, V, dvec, cvec, eps, part, s);
+    if (rg <= 2) return launch_lmhead_wide<2>(W, X, N, V, dvec, cvec, eps, part, s);
+    return launch_lmhead_wide<4>(W, X, N, V, dvec, cvec, eps, part, s);
+  }
   return dec_gemm<DE_ARGMAX, 1>(W, X, N, V, E, dvec, part, nullptr, cvec, eps, nullptr, nullptr, s);
 }
 

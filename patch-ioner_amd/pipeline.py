@@ -29,7 +29,7 @@ class _Group:
         self.ids_dev: Optional[torch.Tensor] = None
         self.counts: List[int] = []
         self.rows = 0
-        self.staged = torch.cuda.Event()
+        self.staged: List[torch.cuda.Event] = []
         self.decoded = torch.cuda.Event()
         self.busy = False
 
@@ -38,20 +38,50 @@ class TraceCaptionPipeline:
     """``for captions in TraceCaptionPipeline(model).run(batches)`` with batches = iterable of (imgs, traces);
     ``traces=None`` captions the CLS token instead (caption_from=cls)."""
 
-    def __init__(self, model, group_batches: int = 4, use_attention_tracing: bool = False, steps: int = 30):
+    def __init__(self, model, group_batches: int = 4, use_attention_tracing: bool = False, steps: int = 30,
+                 stage_replicas: Sequence = (), stage_cus: Optional[int] = None):
+        """``stage_replicas``: further Patchioner instances holding the SAME weights (each has its own ViT
+        workspace); stage 1 of consecutive batches then alternates over the replicas, each on its own stream,
+        so that one batch's GEMM tails, epilogues and launch gaps are filled by the other's kernels."""
         self.m, self.eng = model, model.engine
+        self.stage_models = [model] + list(stage_replicas)
         self.group_batches = group_batches
         self.use_attention_tracing = use_attention_tracing
         self.steps = steps
-        self.sa, self.sb = torch.cuda.Stream(), torch.cuda.Stream()
+        # Stage 1 may be confined to the first `stage_cus` compute units so that the decode's small dependent
+        # kernels find idle CUs instead of queueing behind resident GEMM workgroups (None / 0: no restriction).
+        self._raw_streams = []
+        self.stage_streams = [self._make_stream(stage_cus) for _ in self.stage_models]
+        self.sb = self._make_stream(0)
+        self._nstaged = 0
         cap = self.eng.max_prefixes
         self.groups = [_Group(cap, self.eng.prefix_size, steps, self.eng.device) for _ in range(2)]
         self.last_ids: Optional[torch.Tensor] = None
 
+    def _make_stream(self, n_cus):
+        if not n_cus:
+            return torch.cuda.Stream()
+        from ._lib import load, check
+        import ctypes
+        raw = ctypes.c_void_p()
+        check(load().pio_stream_create(self.eng.device.index or 0, 0, int(n_cus), ctypes.byref(raw)))
+        self._raw_streams.append(raw)
+        return torch.cuda.ExternalStream(raw.value, device=self.eng.device)
+
+    def close(self):
+        from ._lib import load
+        torch.cuda.synchronize()
+        for raw in self._raw_streams:
+            load().pio_stream_destroy(raw)
+        self._raw_streams = []
+
     # ---- stage 1: everything up to the decoder prefix, on stream A ------------------------------------
     def _stage(self, g: _Group, imgs: torch.Tensor, traces) -> None:
-        eng, m = self.eng, self.m
-        with torch.cuda.stream(self.sa):
+        k = self._nstaged % len(self.stage_models)
+        self._nstaged += 1
+        m, stream = self.stage_models[k], self.stage_streams[k]
+        eng = m.engine
+        with torch.cuda.stream(stream):
             tokens, qkv = eng.vit_forward(imgs, want_qkv=traces is not None and self.use_attention_tracing)
             if traces is None:
                 emb = tokens[:, 0].contiguous()
@@ -68,12 +98,16 @@ class TraceCaptionPipeline:
             g.prefix[g.rows:g.rows + n].copy_(pre)
             g.rows += n
             g.counts.append(n)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            g.staged.append(ev)
 
     # ---- stage 2: one decode for the group, on stream B ---------------------------------------------------
     def _decode(self, g: _Group) -> None:
-        g.staged.record(self.sa)
         with torch.cuda.stream(self.sb):
-            self.sb.wait_event(g.staged)
+            for ev in g.staged:
+                self.sb.wait_event(ev)
+            g.staged = []
             ids, _ = self.eng.decode_greedy(g.prefix[:g.rows], steps=self.steps)
             g.ids_dev = ids
             g.ids_host[:g.rows].copy_(ids, non_blocking=True)

@@ -87,3 +87,28 @@ def test_preprocess_and_bbox_adjust():
     assert 0 <= box[0] < 224 and 0 <= box[1] < 224 and box[0] + box[2] <= 224.0001
     crops = process_bboxes([img], torch.tensor([[[10.0, 10.0, 50.0, 60.0], [0.0, 0.0, 100.0, 100.0]]]), t_nc)
     assert crops.shape == (2, 3, 224, 224)
+
+
+def test_inline_asm_weight_loads_are_not_touched_before_their_wait(tmp_path):
+    """k_lmhead_wide hides its weight loads from hipcc in inline asm (decoder.hip); hipcc then knows nothing of
+    their latency, so a compiler copy of a destination register between the load and the s_waitcnt that retires it
+    would read garbage.  Audit the generated ISA of every instantiation (tools/microbench/asm_load_audit.py)."""
+    import re
+    import subprocess
+    import sys
+    asm = tmp_path / "decoder.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.join(ROOT, "patch-ioner_amd", "csrc"), "-S", "--cuda-device-only",
+                    os.path.join(ROOT, "patch-ioner_amd", "csrc", "decoder.hip"), "-o", str(asm)], check=True)
+    text = asm.read_text()
+    names = sorted(set(re.findall(r"^(_ZN3pio13k_lmhead_wide\w+):", text, flags=re.M)))
+    assert len(names) == 3, names
+    for name in names:
+        body = text[text.index(name + ":"):]
+        body = body[:body.index("s_endpgm")]
+        one = tmp_path / (name + ".s")
+        one.write_text(body)
+        assert "scratch_" not in body, name + ": spills next to asm loads"
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "microbench", "asm_load_audit.py"), str(one)],
+                             check=True, capture_output=True, text=True).stdout
+        assert out.startswith("0 violations"), name + ": " + out[:400]
