@@ -213,7 +213,7 @@ def main():
                        "global_batch": BATCH * world, "parallelism": "dp%d (image shards, ids all-gather)" % world, "batches_in_flight_per_gpu": P,
                        "pipelining": "none" if P == 1 else ("one decode per %d batches, overlapped with the next batches' ViT on %d stream(s)" % (P, S)
                                                            if args.mode == "group" else "%d forwards on %d streams" % (P, P))},
-            "roofline": {"kernel": "k_vit_gemm (fp16 MFMA 32x32x16, 60+1 launches/step)", "bound": "mfma",
+            "roofline": {"kernel": "k_vit_gemm (fp16 MFMA 32x32x16, 48+1 launches/step)", "bound": "mfma",
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "avg_launch_us": g["ms"] * 1e3 / max(g["launches"], 1)},
