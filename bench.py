@@ -133,10 +133,12 @@ def main():
                 outs, ids = step()
             return outs, ids
         if pipe is not None:
-            caps = None
+            caps = seen = ids = None
             for caps in pipe.run((imgs, traces) for _ in range(n)):
-                pass
-            return {"trace_capts": caps}, pdist.all_gather_equal_ids(pipe.last_ids[-BATCH:])
+                if pipe.last_ids is not seen:          # a new group was decoded: the path's only exchange, its ids
+                    seen = pipe.last_ids
+                    ids = pdist.all_gather_equal_ids(seen)
+            return {"trace_capts": caps}, ids[-BATCH * world:] if world == 1 else ids.view(world, -1, ids.shape[1])[:, -BATCH:].reshape(-1, ids.shape[1])
         from collections import deque
         pend = deque()
         outs = ids = None
@@ -222,7 +224,7 @@ def main():
                      "note": "one forward at a time (batches_in_flight = 1), the reference eval scripts' call pattern"},
             "stages": stages,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if world > 1:
