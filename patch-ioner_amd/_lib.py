@@ -13,7 +13,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_voi
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpatchioner_hip.so")
+LIB_PATH = os.environ.get("PIO_LIB_PATH") or os.path.join(_HERE, "libpatchioner_hip.so")   # PIO_LIB_PATH: A/B builds of the same ABI (tools/microbench)
 
 
 class PioError(RuntimeError):

@@ -443,11 +443,15 @@ __global__ __launch_bounds__(256, 2) void k_lmhead_wide(const float* __restrict_
   // ordinary load result, which would drain the two-chunk prefetch every chunk.  hipcc does not count asm loads, so
   // the vm queue is counted by hand (PIO_WWAIT names the destinations "+v": no consumer is scheduled above it).
   // Queue order per chunk: W(q) | X(q) | W(q+1): with <= 4 outstanding, W(q) and X(q) have landed.
+  // 64-prefix form (the grouped decode, which runs beside the 1.8 GB bank stream of the next batches): non-temporal,
+  // measured +1.5 % captions/s pipelined; at <= 32 prefixes (one synchronous forward) part of the 154 MB head is
+  // still in the Infinity Cache from the previous step and the default policy is 2.5 % faster end to end.
 #define PIO_WLOAD(set, q)                                                                                      \
   do {                                                                                                         \
     _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                            \
       const float* _p = wp + (q) * CH + 16 * c;                                                                \
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[set][c]) : "v"(_p) : "memory");                  \
+      if constexpr (RG == 4) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(w[set][c]) : "v"(_p) : "memory"); \
+      else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[set][c]) : "v"(_p) : "memory");             \
     }                                                                                                          \
   } while (0)
 #define PIO_WWAIT(set, cnt)                                                                                    \

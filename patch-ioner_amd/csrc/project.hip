@@ -23,6 +23,18 @@
 
 namespace pio {
 
+#ifndef PIO_PROJECT_NT
+#define PIO_PROJECT_NT 1
+#endif
+__device__ __forceinline__ float4 ld_stream4(const float* p) {
+  if (PIO_PROJECT_NT) {
+    const f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+  }
+  return *(const float4*)p;
+}
+
+
 static constexpr int PR_ROWS = 16;   // bank rows per tile
 static constexpr int PR_Q = 16;      // queries per pass
 
@@ -90,8 +102,10 @@ __global__ __launch_bounds__(256, 2) void k_project(const float* __restrict__ ba
   // array that is written in one loop and read in another in scratch).
   static_assert(NV <= 12, "NV");
   float4 g0, g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11;
+  // non-temporal: the bank is read once per call and is 7x the Infinity Cache; a default-policy stream evicts the
+  // ViT / decoder weights that the next kernels want to find there
 #define PIO_BANK_SRC(t, i) \
-  (((const float4*)(bank + (((t) * PR_ROWS + (tid + 256 * (i)) / (D / 4)) < M ? ((t) * PR_ROWS + (tid + 256 * (i)) / (D / 4)) : M - 1) * D))[(tid + 256 * (i)) % (D / 4)])
+  ld_stream4(bank + (((t) * PR_ROWS + (tid + 256 * (i)) / (D / 4)) < M ? ((t) * PR_ROWS + (tid + 256 * (i)) / (D / 4)) : M - 1) * D + 4 * ((tid + 256 * (i)) % (D / 4)))
 #define PIO_BANK_DST(buf, i) \
   (*(float4*)(s_bank + ((tid + 256 * (i)) / (D / 4)) * STRIDE + 4 * ((tid + 256 * (i)) % (D / 4))))
 #define PIO_LOAD_BANK(t)                                  \

@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B build of libpatchioner_hip.so with extra -D flags:  tools/microbench/build_variant.sh NAME -DPIO_X=1 ...
+# -> tools/microbench/bin/libpio_NAME.so   (run with PIO_LIB_PATH=$PWD/tools/microbench/bin/libpio_NAME.so)
+set -e
+cd "$(dirname "$0")/../.."
+name=$1; shift
+out=tools/microbench/bin/var_$name; mkdir -p $out
+for s in api.cpp vit_gemm.hip vit_attention.hip vit_misc.hip region.hip project.hip decoder.hip; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -w -I include -I patch-ioner_amd/csrc "$@" -c patch-ioner_amd/csrc/$s -o $out/${s%.*}.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/microbench/bin/libpio_$name.so $out/*.o
+echo tools/microbench/bin/libpio_$name.so
