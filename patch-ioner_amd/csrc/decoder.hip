@@ -41,6 +41,9 @@ namespace pio {
 #ifndef PIO_DEC_GEMM_WAVES
 #define PIO_DEC_GEMM_WAVES 2
 #endif
+#ifndef PIO_DEC_WAVES_RG4    // waves per k_dec_gemm workgroup at 33..64 prefixes
+#define PIO_DEC_WAVES_RG4 8
+#endif
 #ifndef PIO_LMHEAD_WIDE
 #define PIO_LMHEAD_WIDE 1
 #endif
@@ -63,8 +66,10 @@ __device__ __forceinline__ float gelu_new(float x) {
 }
 
 // out[n][j] = epilogue( sum_k X[n][k] * W[j][k] )        W [Nout][K] ([out][in]), X [N][K]
-//   grid = (ceil(Nout/16), KS) workgroups of 4 waves; each wave owns CPW*16 k's: K = KS * 4 * CPW * 16
-//   (KS = 1: K = 768 or 512; KS = 4: K = 3072).
+//   grid = (ceil(Nout/16), KS) workgroups of NWV waves; each wave owns CPW*16 k's: K = KS * NWV * CPW * 16
+//   (KS = 1: K = 768 or 512; KS = 4: K = 3072).  NWV = 4; 8 at more than 32 prefixes, where the X loads (all of
+//   X per workgroup, 196 KB at 64 rows) set the time: twice the waves = twice the bytes in flight per CU and half
+//   the MFMA chain per wave.
 //   lane (li = lane&15, kq = lane>>4): B operand W[col0+li][k0 + 16c + 4kq + t], A operand X[16g+li][same k]
 //   (the k order inside a chunk is free as long as A and B agree); C: column li, row 4kq+i.
 //   LN != 0: X is the raw residual stream; the LayerNorm is applied algebraically in the epilogue
@@ -73,20 +78,20 @@ __device__ __forceinline__ float gelu_new(float x) {
 //            an agent-scope release + one relaxed atomic ticket per column group; the workgroup that draws the
 //            last ticket acquires, re-reads ALL KS slabs in slice order (so the sum does not depend on which
 //            workgroup was last: deterministic) and runs the epilogue; it also re-arms the counter.
-template <int RG, int CPW, int KS, int EPI, int LN>
-__global__ __launch_bounds__(256, PIO_DEC_GEMM_WAVES) void k_dec_gemm(const float* __restrict__ W, const float* __restrict__ X, int N,
+template <int RG, int CPW, int KS, int EPI, int LN, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? PIO_DEC_GEMM_WAVES : 1) void k_dec_gemm(const float* __restrict__ W, const float* __restrict__ X, int N,
                                                   int Nout, int K, const float* __restrict__ bias, float* out,
                                                   const float* __restrict__ extra, const float* __restrict__ cvec,
                                                   float eps, float* ws, unsigned* cnt) {
-  __shared__ __attribute__((aligned(16))) float red[4 * RG * 256];
-  __shared__ float s_sum[LN ? 4 : 1][RG * 16], s_sq[LN ? 4 : 1][RG * 16];
+  __shared__ __attribute__((aligned(16))) float red[NWV * RG * 256];
+  __shared__ float s_sum[LN ? NWV : 1][RG * 16], s_sq[LN ? NWV : 1][RG * 16];
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int col0 = blockIdx.x * 16;
   const int j = col0 + li;
   const int jc = j < Nout ? j : Nout - 1;
-  const int k0 = (blockIdx.y * 4 + wid) * (16 * CPW) + 4 * kq;
+  const int k0 = (blockIdx.y * NWV + wid) * (16 * CPW) + 4 * kq;
   const float* wp = W + (size_t)jc * K + k0;
   float4 w4[CPW];
 #pragma unroll
@@ -109,21 +114,22 @@ __global__ __launch_bounds__(256, PIO_DEC_GEMM_WAVES) void k_dec_gemm(const floa
     __builtin_amdgcn_sched_barrier(0);
     f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = (f32x4){0.f, 0.f, 0.f, 0.f};   // two independent MFMA chains
     float sx = 0.f, sq = 0.f;
-#define PIO_HALF(xh, wofs)                                                                                     \
-    _Pragma("unroll") for (int c = 0; c < HC; c += 2) {                                                          \
-      a0 = mfma16f(xh[c].x, w4[wofs + c].x, a0);  a1 = mfma16f(xh[c + 1].x, w4[wofs + c + 1].x, a1);             \
-      a0 = mfma16f(xh[c].y, w4[wofs + c].y, a0);  a1 = mfma16f(xh[c + 1].y, w4[wofs + c + 1].y, a1);             \
-      a0 = mfma16f(xh[c].z, w4[wofs + c].z, a0);  a1 = mfma16f(xh[c + 1].z, w4[wofs + c + 1].z, a1);             \
-      a0 = mfma16f(xh[c].w, w4[wofs + c].w, a0);  a1 = mfma16f(xh[c + 1].w, w4[wofs + c + 1].w, a1);             \
-      if (LN) {                                                                                                \
-        sx += ((xh[c].x + xh[c].y) + (xh[c].z + xh[c].w)) + ((xh[c + 1].x + xh[c + 1].y) + (xh[c + 1].z + xh[c + 1].w)); \
-        sq += ((xh[c].x * xh[c].x + xh[c].y * xh[c].y) + (xh[c].z * xh[c].z + xh[c].w * xh[c].w)) +              \
-              ((xh[c + 1].x * xh[c + 1].x + xh[c + 1].y * xh[c + 1].y) + (xh[c + 1].z * xh[c + 1].z + xh[c + 1].w * xh[c + 1].w)); \
-      }                                                                                                        \
+    // chunk pairs (cc, cc+1): even chunks feed chain a0, odd ones a1; chunk cc lives in xa (cc < HC) or xb
+#define PIO_XC(cc) ((cc) < HC ? xa[(cc) < HC ? (cc) : 0] : xb[(cc) < HC ? 0 : (cc) - HC])
+#pragma unroll
+    for (int cc = 0; cc < CPW; cc += 2) {
+      const float4 x0 = PIO_XC(cc), x1 = PIO_XC(cc + 1);
+      a0 = mfma16f(x0.x, w4[cc].x, a0);  a1 = mfma16f(x1.x, w4[cc + 1].x, a1);
+      a0 = mfma16f(x0.y, w4[cc].y, a0);  a1 = mfma16f(x1.y, w4[cc + 1].y, a1);
+      a0 = mfma16f(x0.z, w4[cc].z, a0);  a1 = mfma16f(x1.z, w4[cc + 1].z, a1);
+      a0 = mfma16f(x0.w, w4[cc].w, a0);  a1 = mfma16f(x1.w, w4[cc + 1].w, a1);
+      if (LN) {
+        sx += ((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w));
+        sq += ((x0.x * x0.x + x0.y * x0.y) + (x0.z * x0.z + x0.w * x0.w)) +
+              ((x1.x * x1.x + x1.y * x1.y) + (x1.z * x1.z + x1.w * x1.w));
+      }
     }
-    PIO_HALF(xa, 0)
-    PIO_HALF(xb, HC)
-#undef PIO_HALF
+#undef PIO_XC
     acc[g] = a0 + a1;
     if (LN) {   // row statistics of x: this lane holds 4*CPW values of row 16g+li; sum the 4 kq groups
       sx += __shfl_xor(sx, 16); sx += __shfl_xor(sx, 32);
@@ -138,22 +144,22 @@ __global__ __launch_bounds__(256, PIO_DEC_GEMM_WAVES) void k_dec_gemm(const floa
 #pragma unroll
   for (int g = 0; g < RG; ++g) *(f32x4*)(red + ((wid * RG + g) * 64 + lane) * 4) = acc[g];
   __syncthreads();
-  f32x4 sums[(RG + 3) / 4];
+  f32x4 sums[(RG + NWV - 1) / NWV];
 #pragma unroll
-  for (int gi = 0; gi < (RG + 3) / 4; ++gi) {
-    const int g = wid + 4 * gi;
+  for (int gi = 0; gi < (RG + NWV - 1) / NWV; ++gi) {
+    const int g = wid + NWV * gi;
     if (g < RG) {
       f32x4 s = *(const f32x4*)(red + ((0 * RG + g) * 64 + lane) * 4);
 #pragma unroll
-      for (int w = 1; w < 4; ++w) s += *(const f32x4*)(red + ((w * RG + g) * 64 + lane) * 4);
+      for (int w = 1; w < NWV; ++w) s += *(const f32x4*)(red + ((w * RG + g) * 64 + lane) * 4);
       sums[gi] = s;
     }
   }
   if constexpr (KS > 1) {
     float* slab = ws + ((size_t)blockIdx.x * KS) * RG * 256;
 #pragma unroll
-    for (int gi = 0; gi < (RG + 3) / 4; ++gi) {
-      const int g = wid + 4 * gi;
+    for (int gi = 0; gi < (RG + NWV - 1) / NWV; ++gi) {
+      const int g = wid + NWV * gi;
       if (g < RG) *(f32x4*)(slab + ((size_t)blockIdx.y * RG + g) * 256 + lane * 4) = sums[gi];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its stores
@@ -173,8 +179,8 @@ __global__ __launch_bounds__(256, PIO_DEC_GEMM_WAVES) void k_dec_gemm(const floa
     }
     __syncthreads();
 #pragma unroll
-    for (int gi = 0; gi < (RG + 3) / 4; ++gi) {
-      const int g = wid + 4 * gi;
+    for (int gi = 0; gi < (RG + NWV - 1) / NWV; ++gi) {
+      const int g = wid + NWV * gi;
       if (g < RG) {
         f32x4 s = *(const f32x4*)(slab + ((size_t)0 * RG + g) * 256 + lane * 4);
 #pragma unroll
@@ -184,16 +190,20 @@ __global__ __launch_bounds__(256, PIO_DEC_GEMM_WAVES) void k_dec_gemm(const floa
     }
   }
 #pragma unroll
-  for (int gi = 0; gi < (RG + 3) / 4; ++gi) {
-    const int g = wid + 4 * gi;
+  for (int gi = 0; gi < (RG + NWV - 1) / NWV; ++gi) {
+    const int g = wid + NWV * gi;
     if (g >= RG) continue;
     f32x4 s = sums[gi];
     if (LN) {   // s_i <- r_n (s_i - mu_n c_j) + d_j  for row n = 16g + 4kq + i
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rr = g * 16 + 4 * kq + i;
-        const float tx = (s_sum[0][rr] + s_sum[1][rr]) + (s_sum[2][rr] + s_sum[3][rr]);
-        const float tq = (s_sq[0][rr] + s_sq[1][rr]) + (s_sq[2][rr] + s_sq[3][rr]);
+        float tx = (s_sum[0][rr] + s_sum[1][rr]) + (s_sum[2][rr] + s_sum[3][rr]);
+        float tq = (s_sq[0][rr] + s_sq[1][rr]) + (s_sq[2][rr] + s_sq[3][rr]);
+        if constexpr (NWV == 8) {
+          tx += (s_sum[4][rr] + s_sum[5][rr]) + (s_sum[6][rr] + s_sum[7][rr]);
+          tq += (s_sq[4][rr] + s_sq[5][rr]) + (s_sq[6][rr] + s_sq[7][rr]);
+        }
         const float mu = tx / (float)K;
         const float var = fmaxf(tq / (float)K - mu * mu, 0.f);
         s[i] = rsqrtf(var + eps) * (s[i] - mu * cj) + bj;
@@ -362,13 +372,15 @@ template <int CPW, int KS, int EPI, int LN>
 static hipError_t dec_gemm_rg(const float* W, const float* X, int N, int Nout, int K, const float* bias, float* out,
                               const float* extra, const float* cvec, float eps, float* ws, unsigned* cnt,
                               hipStream_t s) {
-  const dim3 grid(ceil_div(Nout, 16), KS), block(256);
+  const dim3 grid(ceil_div(Nout, 16), KS);
   const int rg = ceil_div(N, 16);
-#define PIO_DG(R) hipLaunchKernelGGL((k_dec_gemm<R, CPW, KS, EPI, LN>), grid, block, 0, s, W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt)
-  if (rg <= 1) PIO_DG(1);
-  else if (rg <= 2) PIO_DG(2);
-  else if (rg <= 4) PIO_DG(4);
-  else return hipErrorInvalidValue;
+#define PIO_DG(R, C, NW) hipLaunchKernelGGL((k_dec_gemm<R, C, KS, EPI, LN, NW>), grid, dim3(64 * NW), 0, s, W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt)
+  if (rg <= 1) PIO_DG(1, CPW, 4);
+  else if (rg <= 2) PIO_DG(2, CPW, 4);
+  else if (rg <= 4) {
+    if constexpr (PIO_DEC_WAVES_RG4 == 8 && CPW % 4 == 0 && EPI != DE_ARGMAX) PIO_DG(4, CPW / 2, 8);
+    else PIO_DG(4, CPW, 4);
+  } else return hipErrorInvalidValue;
 #undef PIO_DG
   return hipGetLastError();
 }
