@@ -185,6 +185,33 @@ def main():
     prof = model.engine.profile_read()
     model.engine.profile_enable(False)
     assert len(outs["trace_capts"]) == BATCH and ids.shape[0] == BATCH * world
+    # Image transforms (the reference times them apart from inference, eval_trace_captioning.py:233-262): 16 camera-sized
+    # RGB images -> [16,3,224,224] on the device (pio_preprocess: raw pixels over PCIe, resize / crop / normalise on the
+    # GPU, bit-exact to PIL) beside the host PIL transform of the mirror.  Not part of `value`.
+    prep = None
+    if rank == 0:
+        try:
+            from PIL import Image
+            import golden_cases as gc
+            raw = [gc.prep_image(300 + i, 640, 480) for i in range(BATCH)]
+            for _ in range(9):                      # every pinned staging slot of the ring allocated (one-off, ~ms each)
+                model.preprocess_images(raw)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for _ in range(20):
+                dev_imgs = model.preprocess_images(raw)
+            torch.cuda.synchronize()
+            dt_dev = (time.perf_counter() - tp) / 20
+            pil = [Image.fromarray(a) for a in raw]
+            tp = time.perf_counter()
+            host_imgs = torch.stack([model.image_transforms(im) for im in pil])
+            dt_host = time.perf_counter() - tp
+            assert torch.equal(dev_imgs.cpu(), host_imgs)
+            prep = {"device_ms_per_batch": dt_dev * 1e3, "device_images_per_s": BATCH / dt_dev,
+                    "host_pil_ms_per_batch": dt_host * 1e3, "input": "16 x 640x480 RGB uint8 (14.7 MB over PCIe)",
+                    "note": "bit-identical outputs; outside the timed region"}
+        except ImportError:
+            pass
     if world > 1:
         t = torch.tensor([dt, dt_sync], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -223,6 +250,7 @@ def main():
                      "ms_per_step": dt_sync / sync_steps * 1e3,
                      "note": "one forward at a time (batches_in_flight = 1), the reference eval scripts' call pattern"},
             "stages": stages,
+            "preprocess": prep,
         }
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
             line["cpu_baseline"] = cpu_baseline()

@@ -186,6 +186,17 @@ typedef enum {
 int pio_profile_enable(pio_handle h, int32_t on);   /* also clears previous records */
 int pio_profile_read(pio_handle h, int32_t cls, double* total_ms, int64_t* launches, double* flops, double* bytes);
 
+/* -- a0: model.image_transforms / image_transforms_no_crop on the device (P/src/model.py:347-357):
+ *    T.Resize(resize_dim, BICUBIC) -> T.CenterCrop(crop_dim) -> T.ToTensor() -> T.Normalize(ImageNet mean / std)
+ *    (mode 0), or T.Resize((resize_dim, resize_dim), BICUBIC) -> ToTensor -> Normalize (mode 1; crop_dim ignored),
+ *    for B RGB uint8 images of different sizes.  Bit-exact to the host pipeline: torchvision's size rules and
+ *    Pillow's two-pass 22-bit fixed-point 8-bit resampler (coefficient tables built on the host per image).
+ *    pixels      : DEVICE, the images packed back to back, each H x W x 3 row-major
+ *    offsets     : HOST, B byte offsets into `pixels`;  wh : HOST, B x (width, height)
+ *    out         : DEVICE fp32 [B][3][S][S], S = crop_dim (mode 0) or resize_dim (mode 1) -- what pio_vit_forward takes */
+int pio_preprocess(pio_handle h, const void* pixels, const int64_t* offsets, const int32_t* wh, int32_t B,
+                   int32_t resize_dim, int32_t crop_dim, int32_t mode, float* out, void* stream);
+
 /* Introspection used by the host mirror and the tests. */
 int pio_num_tokens(pio_handle h);     /* T */
 int pio_grid_side(pio_handle h);      /* n */

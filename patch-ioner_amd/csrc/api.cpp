@@ -108,6 +108,12 @@ struct pio_context {
   float* bank = nullptr; float* bank_inv = nullptr; int64_t bank_rows = 0; int bank_dim = 0;
   float *part_acc = nullptr, *part_ml = nullptr, *sims = nullptr;
   int parts = 512;   // two k_project workgroups per CU
+  // device-side image transforms (pio_preprocess): growable intermediate image, a ring of table slots
+  struct PrepSlot { void* host = nullptr; void* dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; };
+  PrepSlot prep_slots[4];
+  int prep_next = 0;
+  uint8_t* prep_tmp = nullptr; size_t prep_tmp_cap = 0;
+  float* prep_lut = nullptr;
   // live HIP-event profiling (pio_profile_*): one (start, stop) pair per bracketed launch
   struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };
   bool prof_on = false;
@@ -365,6 +371,62 @@ bool is_known_key(const std::string& k) {
   return k.rfind("blocks.", 0) == 0 || k.rfind("decoder.transformer.", 0) == 0 || k.rfind("clip_project.model.0.", 0) == 0;
 }
 
+// ---- Pillow's resampling coefficients (src/libImaging/Resample.c: bicubic_filter, precompute_coeffs,
+//      normalize_coeffs_8bpc), box = the whole axis, for the output samples [first, first + count) only.
+//      Double arithmetic in Pillow's operation order, no FMA contraction: the int tables must be Pillow's bit for bit.
+#pragma clang fp contract(off)
+double pil_bicubic_filter(double x) {
+  const double a = -0.5;
+  if (x < 0.0) x = -x;
+  if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+  if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+  return 0.0;
+}
+
+struct PilAxis { int ksize = 0; std::vector<int32_t> kk, bounds; };
+
+void pil_axis_table(int in_size, int out_size, int first, int count, PilAxis& t) {
+  const double in0 = 0.0, in1 = (double)(float)in_size;
+  const double scale = (in1 - in0) / out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 2.0 * filterscale;
+  t.ksize = (int)ceil(support) * 2 + 1;
+  t.kk.assign((size_t)count * t.ksize, 0);
+  t.bounds.assign((size_t)count * 2, 0);
+  const double ss = 1.0 / filterscale;
+  std::vector<double> w((size_t)t.ksize + 2);
+  for (int i = 0; i < count; ++i) {
+    const int xx = first + i;
+    const double center = in0 + (xx + 0.5) * scale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) {
+      w[x] = pil_bicubic_filter((x + xmin - center + 0.5) * ss);
+      ww += w[x];
+    }
+    for (int x = 0; x < xmax; ++x) {
+      double k = w[x];
+      if (ww != 0.0) k /= ww;
+      t.kk[(size_t)i * t.ksize + x] = k < 0 ? (int)(-0.5 + k * (1 << 22)) : (int)(0.5 + k * (1 << 22));
+    }
+    t.bounds[2 * i] = xmin;
+    t.bounds[2 * i + 1] = xmax;
+  }
+}
+
+// torchvision F.center_crop: origin of the crop window in the coordinates of the (w, h) image (negative = zero padding)
+void center_crop_origin(int w, int h, int crop, int* left, int* top) {
+  const int pl = crop > w ? (crop - w) / 2 : 0, pt = crop > h ? (crop - h) / 2 : 0;
+  const int pw = w + pl + (crop > w ? (crop - w + 1) / 2 : 0), ph = h + pt + (crop > h ? (crop - h + 1) / 2 : 0);
+  if (pw == crop && ph == crop) { *left = -pl; *top = -pt; return; }
+  *left = (int)nearbyint((pw - crop) / 2.0) - pl;   // Python round(): half to even, as nearbyint in the default mode
+  *top = (int)nearbyint((ph - crop) / 2.0) - pt;
+}
+
 }  // namespace
 
 extern "C" {
@@ -437,6 +499,13 @@ int pio_destroy(pio_handle c) {
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
   for (void* p : c->allocs) (void)hipFree(p);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  for (auto& sl : c->prep_slots) {
+    if (sl.host) (void)hipHostFree(sl.host);
+    if (sl.dev) (void)hipFree(sl.dev);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+  }
+  if (c->prep_tmp) (void)hipFree(c->prep_tmp);
+  if (c->prep_lut) (void)hipFree(c->prep_lut);
   if (c->capture_stream) (void)hipStreamDestroy(c->capture_stream);
   delete c;
   return PIO_OK;
@@ -751,6 +820,96 @@ int pio_profile_read(pio_handle c, int32_t cls, double* total_ms, int64_t* launc
     ms += t; fl += r.flops; by += r.bytes; ++n;
   }
   *total_ms = ms; *launches = n; *flops = fl; *bytes = by;
+  return PIO_OK;
+}
+
+int pio_preprocess(pio_handle c, const void* pixels, const int64_t* offsets, const int32_t* wh, int32_t B,
+                   int32_t resize_dim, int32_t crop_dim, int32_t mode, float* out, void* stream) {
+  if (!c || !pixels || !offsets || !wh || !out || B < 1 || resize_dim < 1 || (mode == 0 && crop_dim < 1) || mode < 0 || mode > 1)
+    return fail(PIO_ERR_INVALID_ARG, "pio_preprocess: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_OK(hipSetDevice(c->cfg.device));
+  const int S = mode == 0 ? crop_dim : resize_dim;
+  if (!c->prep_lut) {   // ((v / 255) - mean) / std in IEEE fp32, the operations of ToTensor + Normalize
+    static const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    std::vector<float> lut(768);
+    for (int ch = 0; ch < 3; ++ch)
+      for (int v = 0; v < 256; ++v) {
+        volatile float x = (float)v / 255.0f;
+        volatile float y = x - mean[ch];
+        lut[ch * 256 + v] = y / stdv[ch];
+      }
+    HIP_OK(hipMalloc((void**)&c->prep_lut, 768 * sizeof(float)));
+    HIP_OK(hipMemcpy(c->prep_lut, lut.data(), 768 * sizeof(float), hipMemcpyHostToDevice));
+  }
+  // ---- host: sizes, crop windows and coefficient tables ----
+  std::vector<PrepImage> imgs(B);
+  std::vector<int32_t> tables;
+  size_t tmp_bytes = 0;
+  int max_tmp_elems = 0;
+  PilAxis ax;
+  for (int i = 0; i < B; ++i) {
+    const int w = wh[2 * i], h = wh[2 * i + 1];
+    if (w < 1 || h < 1) return fail(PIO_ERR_INVALID_ARG, "pio_preprocess: empty image");
+    int nw, nh, left = 0, top = 0;
+    if (mode == 0) {   // torchvision F.resize(int): the shorter side becomes resize_dim, the longer int(size * long / short)
+      if (w <= h) { nw = resize_dim; nh = (int)((double)resize_dim * h / w); }
+      else { nh = resize_dim; nw = (int)((double)resize_dim * w / h); }
+      center_crop_origin(nw, nh, crop_dim, &left, &top);
+    } else {
+      nw = nh = resize_dim;
+    }
+    PrepImage& im = imgs[i];
+    im.src = offsets[i]; im.W = w; im.H = h;
+    im.x0 = left < 0 ? -left : 0; im.y0 = top < 0 ? -top : 0;
+    const int cx = left + im.x0, cy = top + im.y0;              // first resized column / row inside the window
+    im.nx = std::min(S - im.x0, nw - cx); im.ny = std::min(S - im.y0, nh - cy);
+    if (im.nx < 0) im.nx = 0;
+    if (im.ny < 0) im.ny = 0;
+    im.r0 = 0; im.nr = 0; im.kh = im.kv = 0; im.coef_h = im.coef_v = im.bnd_h = im.bnd_v = 0; im.tmp = (int64_t)tmp_bytes;
+    if (im.nx > 0 && im.ny > 0) {
+      pil_axis_table(h, nh, cy, im.ny, ax);                      // vertical first: it tells which source rows are needed
+      int r0 = h, r1 = 0;
+      for (int y = 0; y < im.ny; ++y) { r0 = std::min(r0, ax.bounds[2 * y]); r1 = std::max(r1, ax.bounds[2 * y] + ax.bounds[2 * y + 1]); }
+      for (int y = 0; y < im.ny; ++y) ax.bounds[2 * y] -= r0;
+      im.r0 = r0; im.nr = r1 - r0; im.kv = ax.ksize;
+      im.coef_v = (int32_t)tables.size(); tables.insert(tables.end(), ax.kk.begin(), ax.kk.end());
+      im.bnd_v = (int32_t)tables.size(); tables.insert(tables.end(), ax.bounds.begin(), ax.bounds.end());
+      pil_axis_table(w, nw, cx, im.nx, ax);
+      im.kh = ax.ksize;
+      im.coef_h = (int32_t)tables.size(); tables.insert(tables.end(), ax.kk.begin(), ax.kk.end());
+      im.bnd_h = (int32_t)tables.size(); tables.insert(tables.end(), ax.bounds.begin(), ax.bounds.end());
+      tmp_bytes += (size_t)im.nr * im.nx * 3;
+      tmp_bytes = (tmp_bytes + 15) & ~(size_t)15;
+      max_tmp_elems = std::max(max_tmp_elems, im.nr * im.nx);
+    }
+  }
+  // ---- staging: [PrepImage x B | tables] through one pinned slot of the ring, one asynchronous copy ----
+  const size_t img_bytes = (size_t)B * sizeof(PrepImage), tab_bytes = tables.size() * sizeof(int32_t);
+  const size_t need = img_bytes + tab_bytes + 16;
+  pio_context::PrepSlot& sl = c->prep_slots[c->prep_next];
+  c->prep_next = (c->prep_next + 1) % 4;
+  if (sl.done) HIP_OK(hipEventSynchronize(sl.done));            // the launch that last used this slot has finished
+  else HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  if (sl.cap < need) {
+    if (sl.host) HIP_OK(hipHostFree(sl.host));
+    if (sl.dev) HIP_OK(hipFree(sl.dev));
+    sl.cap = need * 2;
+    HIP_OK(hipHostMalloc(&sl.host, sl.cap, hipHostMallocDefault));
+    HIP_OK(hipMalloc(&sl.dev, sl.cap));
+  }
+  if (c->prep_tmp_cap < tmp_bytes) {
+    HIP_OK(hipStreamSynchronize(s));                             // nobody is still reading the old intermediate image
+    if (c->prep_tmp) HIP_OK(hipFree(c->prep_tmp));
+    c->prep_tmp_cap = tmp_bytes * 2;
+    HIP_OK(hipMalloc((void**)&c->prep_tmp, c->prep_tmp_cap));
+  }
+  memcpy(sl.host, imgs.data(), img_bytes);
+  memcpy((char*)sl.host + img_bytes, tables.data(), tab_bytes);
+  HIP_OK(hipMemcpyAsync(sl.dev, sl.host, img_bytes + tab_bytes, hipMemcpyHostToDevice, s));
+  HIP_OK(launch_preprocess((const uint8_t*)pixels, (const PrepImage*)sl.dev, (const int32_t*)((const char*)sl.dev + img_bytes),
+                           c->prep_tmp, c->prep_lut, B, S, max_tmp_elems, out, s));
+  HIP_OK(hipEventRecord(sl.done, s));
   return PIO_OK;
 }
 

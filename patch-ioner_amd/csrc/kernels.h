@@ -123,6 +123,19 @@ struct DecoderArgs {
   float* logprob;    // [N][steps] or null
 };
 hipError_t launch_decode_greedy(const DecoderArgs& a, hipStream_t s);
+// ---- preprocess.hip: image_transforms on the device (P/src/model.py:347-357; Pillow's 8-bit two-pass resampler) ----
+struct PrepImage {
+  int64_t src;                              // byte offset of the image's first pixel in `pixels` (RGB, HWC, row-major)
+  int64_t tmp;                              // byte offset of its intermediate image [nr][nx][3] in `tmp`
+  int32_t W, H;                             // source size
+  int32_t x0, y0, nx, ny;                   // output window [y0, y0+ny) x [x0, x0+nx) that holds image content
+  int32_t kh, kv;                           // taps per output column / row (strides of the coefficient tables)
+  int32_t r0, nr;                           // first source row the vertical pass needs, number of such rows
+  int32_t coef_h, coef_v, bnd_h, bnd_v;     // int32 offsets into `tables`: coefficients [n][k], bounds [n][2] = (min, count)
+};
+hipError_t launch_preprocess(const uint8_t* pixels, const PrepImage* imgs, const int32_t* tables, uint8_t* tmp,
+                             const float* lut, int B, int S, int max_tmp_elems, float* out, hipStream_t s);
+
 hipError_t decoder_init();   // one-time function attributes (call outside stream capture)
 
 }  // namespace pio

@@ -194,6 +194,50 @@ class Engine:
                                         ptr(weights), 1 if single_map else 0, ptr(single), _stream()))
         return weights, single
 
+    def preprocess(self, images: Sequence, resize_dim: int, crop_dim: int, no_crop: bool = False) -> torch.Tensor:
+        """image_transforms / image_transforms_no_crop (P/src/model.py:347-357) for a list of RGB images of different
+        sizes (PIL images or uint8 [H][W][3] arrays / tensors) -> fp32 [B][3][S][S] on the device, bit-exact to the
+        host PIL pipeline.  The raw pixels cross PCIe once (pinned staging, one asynchronous copy); resize, crop and
+        normalisation run on the GPU (pio_preprocess)."""
+        arrs = []
+        for im in images:
+            if isinstance(im, torch.Tensor):
+                a = im.detach().cpu().numpy()
+            elif isinstance(im, np.ndarray):
+                a = im
+            else:
+                a = np.asarray(im.convert("RGB"))
+            if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+                raise ValueError("preprocess expects RGB uint8 [H][W][3] images")
+            arrs.append(np.ascontiguousarray(a))
+        B = len(arrs)
+        sizes = np.array([(a.shape[1], a.shape[0]) for a in arrs], dtype=np.int32)
+        nbytes = [a.size for a in arrs]
+        offsets = np.zeros(B, dtype=np.int64)
+        offsets[1:] = np.cumsum([(n + 15) // 16 * 16 for n in nbytes])[:-1]
+        total = int(offsets[-1] + nbytes[-1])
+        slot = self._stage_ring[self._stage_next % len(self._stage_ring)]
+        self._stage_next += 1
+        if slot["event"] is not None:
+            slot["event"].synchronize()
+        if slot["host"] is None or slot["host"].numel() < total:
+            cap = max(1 << 16, 2 * total)
+            slot["host"] = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            slot["dev"] = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        host = slot["host"].numpy()
+        for a, o, n in zip(arrs, offsets, nbytes):
+            host[o:o + n] = a.reshape(-1)
+        slot["dev"][:total].copy_(slot["host"][:total], non_blocking=True)
+        S = resize_dim if no_crop else crop_dim
+        out = torch.empty(B, 3, S, S, device=self.device, dtype=torch.float32)
+        check(self.lib.pio_preprocess(self.h, slot["dev"].data_ptr(), offsets.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                      sizes.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), B, int(resize_dim), int(crop_dim),
+                                      1 if no_crop else 0, ptr(out), _stream()))
+        if slot["event"] is None:
+            slot["event"] = torch.cuda.Event()
+        slot["event"].record(torch.cuda.current_stream())
+        return out
+
     def region_reduce(self, tokens: torch.Tensor, weights: torch.Tensor, img_index: Optional[torch.Tensor],
                       scale: float) -> torch.Tensor:
         """out[r] = scale * sum_p weights[r,p] * patch_tokens[img_index[r], p]"""

@@ -435,6 +435,11 @@ class Patchioner(nn.Module):
         return eng.region_reduce(tokens, weights, idx, 1.0).view(B, NB, self.embed_dim)
 
     # ------------------------------------------------------------------------------------------
+    def preprocess_images(self, images, no_crop: bool = False):
+        """Device-side ``torch.stack([self.image_transforms(im) for im in images]).to(device)`` (``no_crop``:
+        ``image_transforms_no_crop``): same floats, computed on the GPU from the raw pixels (Engine.preprocess)."""
+        return self.engine.preprocess(images, self.resize_dim, self.crop_dim, no_crop=no_crop)
+
     def caption_bboxes(self, imgs, bboxes, capt_type='cls_capt', crop_boxes=False, compute_scores=False):
         """P/src/model.py:1356-1390: crop each box from the PIL image and caption the crop."""
         bs = len(imgs)

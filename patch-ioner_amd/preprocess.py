@@ -17,6 +17,18 @@ def _to_tensor_normalized(img) -> torch.Tensor:
     return torch.from_numpy((arr - _MEAN) / _STD)
 
 
+def center_crop_origin(w: int, h: int, crop: int):
+    """torchvision F.center_crop: (left, top) of the crop window in the coordinates of the (w, h) image; negative where
+    the image is smaller than the crop (zero padding of (crop - dim) // 2 before and (crop - dim + 1) // 2 after)."""
+    pl = (crop - w) // 2 if crop > w else 0
+    pt = (crop - h) // 2 if crop > h else 0
+    pw = w + pl + ((crop - w + 1) // 2 if crop > w else 0)
+    ph = h + pt + ((crop - h + 1) // 2 if crop > h else 0)
+    if pw == crop and ph == crop:
+        return -pl, -pt
+    return int(round((pw - crop) / 2.0)) - pl, int(round((ph - crop) / 2.0)) - pt
+
+
 class ResizeCropTransform:
     """T.Compose([T.Resize(resize_dim, BICUBIC), T.CenterCrop(crop_dim), T.ToTensor(), T.Normalize(...)])"""
 
@@ -32,10 +44,9 @@ class ResizeCropTransform:
         else:
             nw, nh = int(s * w / h), s
         img = img.resize((nw, nh), Image.BICUBIC)
+        left, top = center_crop_origin(nw, nh, self.crop_dim)
         c = self.crop_dim
-        left = int(round((nw - c) / 2.0))
-        top = int(round((nh - c) / 2.0))
-        img = img.crop((left, top, left + c, top + c))      # PIL pads with zeros outside, like torchvision's pad+crop
+        img = img.crop((left, top, left + c, top + c))      # PIL fills with zeros outside the image = the pad
         return _to_tensor_normalized(img)
 
 

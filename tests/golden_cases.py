@@ -144,3 +144,22 @@ def e2e_boxes():
     b = np.concatenate([xy, wh], axis=-1).astype(np.float32)
     b[:, 2] = [0.0, 0.0, 1.0, 1.0]      # dense-captioning pad box (eval_densecap.py:332-333)
     return torch.tensor(b)
+
+
+# ---- image transforms -------------------------------------------------------------------
+# (w, h, new_w, new_h): down- and up-scaling, odd sizes, extreme aspect, identity on one axis
+PREP_RESIZE_CASES = [(64, 48, 30, 22), (50, 37, 29, 22), (10, 8, 28, 22), (33, 50, 22, 33), (22, 22, 22, 22),
+                     (5, 100, 22, 440), (96, 72, 22, 22), (7, 5, 22, 22), (40, 30, 40, 17)]
+# (w, h, resize_dim, crop_dim) for the whole transform, incl. resize_dim < crop_dim (zero padding, odd differences)
+PREP_TRANSFORM_CASES = [(640, 480, 224, 224), (375, 500, 256, 224), (100, 300, 224, 224), (224, 224, 224, 224),
+                        (900, 200, 518, 518), (60, 50, 224, 224), (200, 150, 160, 224), (201, 150, 160, 224),
+                        (150, 313, 100, 224), (300, 100, 37, 224), (1023, 767, 224, 224)]
+
+
+def prep_image(seed, w, h):
+    """Seeded RGB uint8 image with smooth structure plus noise (exercises clipping at 0 / 255)."""
+    rng = np.random.RandomState(1000 + seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = 127.5 + 127.5 * np.sin(xx[..., None] / (3.0 + np.arange(3)) + yy[..., None] / (5.0 - np.arange(3)))
+    img = base + rng.randint(-90, 91, size=(h, w, 3))
+    return np.clip(img, 0, 255).astype(np.uint8)
