@@ -186,6 +186,16 @@ typedef enum {
 int pio_profile_enable(pio_handle h, int32_t on);   /* also clears previous records */
 int pio_profile_read(pio_handle h, int32_t cls, double* total_ms, int64_t* launches, double* flops, double* bytes);
 
+/* -- f.2: extract_bboxes_feats_double_dino (P/src/bbox_utils.py:300-403, called at model.py:983-992): for every
+ *    (image, box) re-run the LAST ViT block on [cls | registers | the box's region patches] of the final tokens
+ *    (cls / registers only with use_cls) and return row 0 (return_type 0, "cls") or the mean of the region rows
+ *    (1, "avg"; NaN for an empty region).  "gaussian_avg" of the reference weights the INPUT patches and does not
+ *    need the block: the host mirror builds those weights and calls pio_region_reduce.
+ *    tokens [B][T][D] fp32 (pio_vit_forward output); slices DEVICE int32 [B*NB][4] = (y_start, y_end, x_start, x_end)
+ *    patch-grid slices after Python slice normalisation; out [B*NB][D].  Sequences run in chunks of max_batch. */
+int pio_bbox_double_dino(pio_handle h, const float* tokens, const int32_t* slices, int32_t B, int32_t NB, int32_t use_cls,
+                         int32_t return_type, float* out, pio_stream stream);
+
 /* -- a0: model.image_transforms / image_transforms_no_crop on the device (P/src/model.py:347-357):
  *    T.Resize(resize_dim, BICUBIC) -> T.CenterCrop(crop_dim) -> T.ToTensor() -> T.Normalize(ImageNet mean / std)
  *    (mode 0), or T.Resize((resize_dim, resize_dim), BICUBIC) -> ToTensor -> Normalize (mode 1; crop_dim ignored),

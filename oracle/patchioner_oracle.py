@@ -168,6 +168,55 @@ def trace_embeds(patch_tokens: torch.Tensor, traces: Sequence[Sequence[dict]],
 # --------------------------------------------------------------------------------------------
 
 
+def extract_bboxes_feats_double_dino(vit: "DinoV2Oracle", patch_embeddings: torch.Tensor, bboxes: torch.Tensor,
+                                     cls_token: Optional[torch.Tensor], registers_tokens: Optional[torch.Tensor],
+                                     patch_size: int, return_type: str = "cls", gaussian_bbox_variance: float = 0.5):
+    """P/src/bbox_utils.py:300-403: per (image, box) re-run the LAST block on [cls | registers | region patches] of
+    the final tokens.  Quirks kept: the xywh tensor is floor-divided by the patch size (on a clone) and then read as
+    (x1, y1, x2, y2) with inclusive python slices; "gaussian_avg" weights the block's INPUT patches, normalised to
+    sum 1 (an empty region gives zeros), "avg" is the mean of the block's OUTPUT region rows (NaN when empty)."""
+    N, N_boxes = patch_embeddings.shape[0], bboxes.shape[1]
+    g = int(patch_embeddings.shape[1] ** 0.5)
+    D = patch_embeddings.shape[-1]
+    idx = bboxes.clone()
+    idx //= patch_size
+    idx = idx.int()
+    pe = patch_embeddings.view(N, g, g, D)
+    if cls_token is not None:
+        off = 5 if registers_tokens is not None else 1
+    else:
+        assert return_type != "cls"
+        off = 0
+    last = vit.depth - 1
+    means = []
+    for i in range(N):
+        image_means = []
+        for j in range(N_boxes):
+            region_xy = pe[i, idx[i, j, 1]:idx[i, j, 3] + 1, idx[i, j, 0]:idx[i, j, 2] + 1, :]
+            region = region_xy.reshape(1, -1, D)
+            parts = []
+            if cls_token is not None:
+                parts.append(cls_token[i].reshape(1, 1, D))
+                if registers_tokens is not None:
+                    parts.append(registers_tokens[i].reshape(1, 4, D))
+            parts.append(region)
+            outputs = vit.block(last, torch.cat(parts, dim=1))
+            rows = outputs[0, off:]
+            if return_type == "gaussian_avg":
+                h_span, w_span = region_xy.shape[:2]
+                yc, xc = torch.meshgrid(torch.linspace(-1, 1, h_span), torch.linspace(-1, 1, w_span), indexing="ij")
+                wts = torch.exp(-(xc ** 2 + yc ** 2) / gaussian_bbox_variance)
+                wts = wts / wts.sum()
+                mean = (region_xy * wts.unsqueeze(-1)).sum(dim=(0, 1))
+            elif return_type == "avg":
+                mean = rows.mean(dim=0)
+            else:
+                mean = outputs[0, 0]
+            image_means.append(mean)
+        means.append(torch.stack(image_means))
+    return torch.stack(means)
+
+
 def extract_bboxes_feats(patch_embeddings: torch.Tensor, bboxes: torch.Tensor, gaussian_avg=False,
                          gaussian_bbox_variance=0.5, get_single_embedding_per_image=False,
                          patch_size=14, attention_map: Optional[torch.Tensor] = None,

@@ -88,6 +88,7 @@ struct pio_context {
   // ViT workspaces
   float* x = nullptr; void* xn = nullptr; void* ao = nullptr; void* hbuf = nullptr; void* ape = nullptr;
   void *q = nullptr, *k = nullptr, *vT = nullptr;
+  int32_t* seq_lens = nullptr;   // double-DINO boxes: token count of each sequence of the current chunk
   // read-out workspaces
   float* head_logits = nullptr; float* head_sm = nullptr; int32_t* head_img = nullptr;
   // decoder weights
@@ -607,6 +608,41 @@ int pio_set_memory_bank_device(pio_handle c, const float* dev_bank, int64_t rows
   return bank_common(c, rows, dim);
 }
 
+// One pre-LN DINOv2 block on the B sequences of c->x (in place): LN1 -> qkv -> attention -> proj (+LayerScale,
+// +residual) -> LN2 -> fc1 + GELU -> fc2 (+LayerScale, +residual).  `at.lens` (optional) = per-sequence token counts.
+static int run_vit_block(pio_handle c, const VitLayerDev& L, int B, const GemmArgs& g, const VitAttnArgs& at,
+                         float* qkv_last, hipStream_t s) {
+  const int D = c->D, M = B * c->Tp;
+  const double Malg = (double)B * c->T;   // algorithmic rows: no pad tokens
+  PROF(c, PIO_PROF_VIT_LN, 0, Malg * D * 6.0, s,
+       launch_layernorm(c->op, c->x, L.n1w, L.n1b, c->cfg.vit_ln_eps, M, D, c->xn, nullptr, c->T, c->Tp, s));
+  {
+    GemmArgs a = g;
+    a.A = c->xn; a.lda = D; a.W = L.qkvw; a.bias = L.qkvb; a.M = M; a.N = 3 * D; a.K = D;
+    a.qkv_last = qkv_last;
+    PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * 3.0 * D * D, 0, s, launch_vit_gemm(c->op, EPI_QKV, a, s));
+  }
+  PROF(c, PIO_PROF_VIT_ATTN, 4.0 * B * (double)c->T * c->T * D, 0, s, launch_vit_attention(c->op, at, s));
+  {
+    GemmArgs a = g;
+    a.A = c->ao; a.lda = D; a.W = L.projw; a.bias = L.projb; a.ls = L.ls1; a.M = M; a.N = D; a.K = D;
+    PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * D * D, 0, s, launch_vit_gemm(c->op, EPI_RESIDUAL, a, s));
+  }
+  PROF(c, PIO_PROF_VIT_LN, 0, Malg * D * 6.0, s,
+       launch_layernorm(c->op, c->x, L.n2w, L.n2b, c->cfg.vit_ln_eps, M, D, c->xn, nullptr, c->T, c->Tp, s));
+  {
+    GemmArgs a = g;
+    a.A = c->xn; a.lda = D; a.W = L.fc1w; a.bias = L.fc1b; a.out16 = c->hbuf; a.M = M; a.N = 4 * D; a.K = D;
+    PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * 4.0 * D * D, 0, s, launch_vit_gemm(c->op, EPI_GELU, a, s));
+  }
+  {
+    GemmArgs a = g;
+    a.A = c->hbuf; a.lda = 4 * D; a.W = L.fc2w; a.bias = L.fc2b; a.ls = L.ls2; a.M = M; a.N = D; a.K = 4 * D;
+    PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * 4.0 * D * D, 0, s, launch_vit_gemm(c->op, EPI_RESIDUAL, a, s));
+  }
+  return PIO_OK;
+}
+
 int pio_vit_forward(pio_handle c, const float* imgs, int32_t B, float* tokens, float* qkv_last, pio_stream stream) {
   if (!c || !imgs || !tokens) return fail(PIO_ERR_INVALID_ARG, "pio_vit_forward: null argument");
   if (!c->has_vit) return fail(PIO_ERR_NOT_READY, "pio_vit_forward: backbone weights not loaded");
@@ -614,7 +650,6 @@ int pio_vit_forward(pio_handle c, const float* imgs, int32_t B, float* tokens, f
   HIP_OK(hipSetDevice(c->cfg.device));
   hipStream_t s = (hipStream_t)stream;
   const int D = c->D, M = B * c->Tp;
-  const double Malg = (double)B * c->T;   // algorithmic rows: no pad tokens
   HIP_OK(launch_im2col(c->op, imgs, B, c->cfg.crop_dim, c->cfg.patch_size, c->n, c->Kpad, c->ape, s));
   HIP_OK(launch_token_init(c->x, c->cls, c->pos, c->reg, B, c->cfg.num_registers, c->T, c->Tp, D, s));
   GemmArgs g;
@@ -631,35 +666,43 @@ int pio_vit_forward(pio_handle c, const float* imgs, int32_t B, float* tokens, f
   at.Tk = c->Tk; at.D = D; at.scale = 0.125f;  // 64^-0.5
   const int depth = c->cfg.depth;
   for (int l = 0; l < depth; ++l) {
-    const VitLayerDev& L = c->vl[l];
-    PROF(c, PIO_PROF_VIT_LN, 0, Malg * D * 6.0, s,
-         launch_layernorm(c->op, c->x, L.n1w, L.n1b, c->cfg.vit_ln_eps, M, D, c->xn, nullptr, c->T, c->Tp, s));
-    {
-      GemmArgs a = g;
-      a.A = c->xn; a.lda = D; a.W = L.qkvw; a.bias = L.qkvb; a.M = M; a.N = 3 * D; a.K = D;
-      a.qkv_last = (l == depth - 1) ? qkv_last : nullptr;
-      PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * 3.0 * D * D, 0, s, launch_vit_gemm(c->op, EPI_QKV, a, s));
-    }
-    PROF(c, PIO_PROF_VIT_ATTN, 4.0 * B * (double)c->T * c->T * D, 0, s, launch_vit_attention(c->op, at, s));
-    {
-      GemmArgs a = g;
-      a.A = c->ao; a.lda = D; a.W = L.projw; a.bias = L.projb; a.ls = L.ls1; a.M = M; a.N = D; a.K = D;
-      PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * D * D, 0, s, launch_vit_gemm(c->op, EPI_RESIDUAL, a, s));
-    }
-    PROF(c, PIO_PROF_VIT_LN, 0, Malg * D * 6.0, s,
-         launch_layernorm(c->op, c->x, L.n2w, L.n2b, c->cfg.vit_ln_eps, M, D, c->xn, nullptr, c->T, c->Tp, s));
-    {
-      GemmArgs a = g;
-      a.A = c->xn; a.lda = D; a.W = L.fc1w; a.bias = L.fc1b; a.out16 = c->hbuf; a.M = M; a.N = 4 * D; a.K = D;
-      PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * 4.0 * D * D, 0, s, launch_vit_gemm(c->op, EPI_GELU, a, s));
-    }
-    {
-      GemmArgs a = g;
-      a.A = c->hbuf; a.lda = 4 * D; a.W = L.fc2w; a.bias = L.fc2b; a.ls = L.ls2; a.M = M; a.N = D; a.K = 4 * D;
-      PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * 4.0 * D * D, 0, s, launch_vit_gemm(c->op, EPI_RESIDUAL, a, s));
-    }
+    const int rc = run_vit_block(c, c->vl[l], B, g, at, (l == depth - 1) ? qkv_last : nullptr, s);
+    if (rc != PIO_OK) return rc;
   }
   HIP_OK(launch_layernorm(c->op, c->x, c->norm_w, c->norm_b, c->cfg.vit_ln_eps, M, D, nullptr, tokens, c->T, c->Tp, s));
+  return PIO_OK;
+}
+
+int pio_bbox_double_dino(pio_handle c, const float* tokens, const int32_t* slices, int32_t B, int32_t NB, int32_t use_cls,
+                         int32_t return_type, float* out, pio_stream stream) {
+  if (!c || !tokens || !slices || !out) return fail(PIO_ERR_INVALID_ARG, "pio_bbox_double_dino: null argument");
+  if (!c->has_vit) return fail(PIO_ERR_NOT_READY, "pio_bbox_double_dino: backbone weights not loaded");
+  if (B < 1 || NB < 1) return fail(PIO_ERR_INVALID_ARG, "pio_bbox_double_dino: empty batch");
+  if (return_type < 0 || return_type > 1) return fail(PIO_ERR_INVALID_ARG, "pio_bbox_double_dino: return_type 0 (cls) or 1 (avg)");
+  if (return_type == 0 && !use_cls) return fail(PIO_ERR_INVALID_ARG, "pio_bbox_double_dino: return_type cls needs use_cls");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  if (!c->seq_lens) {
+    const int rc = c->dmalloc(&c->seq_lens, (size_t)c->cfg.max_batch);
+    if (rc != PIO_OK) return rc;
+  }
+  const int D = c->D, Ns = B * NB, Gs = use_cls ? c->G : 0;
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.T = c->T; g.Tp = c->Tp; g.Tk = c->Tk; g.G = c->G; g.n2 = c->n2; g.D = D; g.H = c->H;
+  g.x = c->x; g.pos = c->pos; g.q = c->q; g.k = c->k; g.vT = c->vT;
+  VitAttnArgs at;
+  at.q = c->q; at.k = c->k; at.vT = c->vT; at.out = c->ao; at.H = c->H; at.T = c->T; at.Tp = c->Tp;
+  at.Tk = c->Tk; at.D = D; at.scale = 0.125f; at.lens = c->seq_lens;
+  const VitLayerDev& L = c->vl[c->cfg.depth - 1];
+  for (int s0 = 0; s0 < Ns; s0 += c->cfg.max_batch) {         // chunks of max_batch sequences through the ViT workspace
+    const int ns = std::min(c->cfg.max_batch, Ns - s0);
+    at.B = ns;
+    HIP_OK(launch_box_sequences(tokens, slices, s0, ns, NB, c->T, c->Tp, c->G, c->n, D, use_cls, c->x, c->seq_lens, s));
+    const int rc = run_vit_block(c, L, ns, g, at, nullptr, s);
+    if (rc != PIO_OK) return rc;
+    HIP_OK(launch_box_seq_reduce(c->x, c->seq_lens, ns, c->Tp, D, Gs, return_type, out + (size_t)s0 * D, s));
+  }
   return PIO_OK;
 }
 

@@ -59,6 +59,16 @@ __device__ __forceinline__ f32x4 mfma16f(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// torch.argmax order: NaN counts as the maximum, ties (and several NaNs) go to the lowest index.  A prefix of NaNs
+// (the reference's mean over an empty box region) therefore decodes to token 0, as in the reference, instead of
+// leaving the arg-max at its sentinel.
+__device__ __forceinline__ bool arg_better(float v, int i, float best, int bi) {
+  const bool vn = v != v, bn = best != best;
+  if (vn != bn) return vn;
+  if (vn) return i < bi;
+  return v > best || (v == best && i < bi);
+}
+
 __device__ __forceinline__ float gelu_new(float x) {
   // transformers "gelu_new": 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? PIO_DEC_GEMM_WAVES : 1) void k
         for (int o = 1; o < 16; o <<= 1) {
           const float ov = __shfl_xor(mx, o);
           const int oi = __shfl_xor(idx, o);
-          if (ov > mx || (ov == mx && oi < idx)) { mx = ov; idx = oi; }
+          if (arg_better(ov, oi, mx, idx)) { mx = ov; idx = oi; }
         }
         float se = j < Nout ? expf(v - mx) : 0.f;
 #pragma unroll
@@ -339,20 +349,20 @@ __global__ __launch_bounds__(256) void k_dec_select(const float* __restrict__ pa
   for (int k = 0; k < 16; ++k) {
     const float v = pr[k].x;
     const int i = __float_as_int(pr[k].y);
-    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    if (arg_better(v, i, bv, bi)) { bv = v; bi = i; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float ov = __shfl_xor(bv, o);
     const int oi = __shfl_xor(bi, o);
-    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    if (arg_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
   }
   if (lane == 0) { s_v[wid] = bv; s_i[wid] = bi; }
   __syncthreads();
   bv = s_v[0]; bi = s_i[0];
 #pragma unroll
   for (int w = 1; w < 4; ++w)
-    if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) { bv = s_v[w]; bi = s_i[w]; }
+    if (arg_better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
   for (int d = tid; d < E; d += 256) x[(size_t)n * E + d] = wte[(size_t)bi * E + d] + wpe[(size_t)(step + 1) * E + d];
   {
     float se = 0.f;
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void k_lmhead_wide(const float* __restrict_
       for (int o = 1; o < 16; o <<= 1) {
         const float ov = __shfl_xor(mx, o);
         const int oi = __shfl_xor(idx, o);
-        if (ov > mx || (ov == mx && oi < idx)) { mx = ov; idx = oi; }
+        if (arg_better(ov, oi, mx, idx)) { mx = ov; idx = oi; }
       }
       float se = j < V ? expf(v - mx) : 0.f;
 #pragma unroll

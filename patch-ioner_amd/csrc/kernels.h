@@ -40,6 +40,7 @@ struct VitAttnArgs {
   void* out;       // [B*Tp][D] operand type
   int B, H, T, Tp, Tk, D;
   float scale;     // head_dim^-0.5
+  const int32_t* lens = nullptr;   // optional [B]: tokens of each sequence (keys >= lens[b] are masked); else T for all
 };
 hipError_t launch_vit_attention(OperandType t, const VitAttnArgs& a, hipStream_t s);
 
@@ -50,6 +51,13 @@ hipError_t launch_layernorm(OperandType t, const float* x, const float* w, const
 hipError_t launch_im2col(OperandType t, const float* imgs, int B, int S, int p, int n, int Kpad, void* out,
                          hipStream_t s);
 // x[b][0] = cls + pos[0]; x[b][1..R] = registers; x[b][T..Tp-1] = 0
+// double-DINO boxes (P/src/bbox_utils.py:300-403): sequence s = (image, box) -> x[s] = [cls | registers | region patches]
+// (final tokens; `slices` [Ns][4] = python-normalised ys, ye, xs, xe), zero rows up to Tp; lens[s] = its token count
+hipError_t launch_box_sequences(const float* tokens, const int32_t* slices, int s_base, int Ns, int NB, int T, int Tp, int G,
+                                int n, int D, int use_global, float* x, int32_t* lens, hipStream_t s);
+// after the block: mode 0 = row 0 (cls), 1 = mean of rows [G_s, lens) (NaN for an empty region, like torch.mean)
+hipError_t launch_box_seq_reduce(const float* x, const int32_t* lens, int Ns, int Tp, int D, int Gs, int mode, float* out,
+                                 hipStream_t s);
 hipError_t launch_token_init(float* x, const float* cls, const float* pos0, const float* reg, int B, int R, int T,
                              int Tp, int D, hipStream_t s);
 

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256, 2) void k_vit_attention(const VitAttnArgs a) {
   const int h = lane >> 5, r31 = lane & 31;
   const int bh = blockIdx.y;                 // b*H + head
   const int b = bh / a.H, head = bh - b * a.H;
+  const int nkeys = a.lens ? a.lens[b] : a.T;     // keys of this sequence (block-uniform)
   const int q0 = blockIdx.x * 128 + wid * 32;
   const bool active = q0 < a.Tp;             // wave-uniform
   const T* qb = (const T*)a.q + (size_t)bh * a.Tk * 64;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void k_vit_attention(const VitAttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
 
-  const int nkt = (a.T + KV_TILE - 1) / KV_TILE;
+  const int nkt = nkeys > 0 ? (nkeys + KV_TILE - 1) / KV_TILE : 1;
   PIO_LOAD_KV(0);
   PIO_STORE_KV(0);
   __syncthreads();
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void k_vit_attention(const VitAttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kt * KV_TILE + kbk * 32 + acc_row32(r, lane);
-          const float z = key < a.T ? st[kbk][r] * sl2 : -1e30f;
+          const float z = key < nkeys ? st[kbk][r] * sl2 : -1e30f;
           st[kbk][r] = z;
           mx = fmaxf(mx, z);
         }

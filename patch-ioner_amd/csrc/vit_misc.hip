@@ -126,4 +126,53 @@ hipError_t launch_token_init(float* x, const float* cls, const float* pos0, cons
   return hipGetLastError();
 }
 
+
+// ---- double-DINO boxes: gather the block input of every (image, box) sequence ------------------------------
+__global__ __launch_bounds__(256) void k_box_sequences(const float* __restrict__ tokens, const int32_t* __restrict__ slices,
+                                                       int s_base, int NB, int T, int Tp, int G, int n, int D, int use_global,
+                                                       float* __restrict__ x, int32_t* __restrict__ lens) {
+  const int s = blockIdx.y, t = blockIdx.x;      // s: sequence inside this chunk; s_base + s: (image, box) index
+  const int b = (s_base + s) / NB;
+  const int32_t* sl = slices + 4 * (size_t)(s_base + s);
+  const int ys = sl[0], ye = sl[1], xs = sl[2], xe = sl[3];
+  const int hh = ye > ys ? ye - ys : 0, ww = xe > xs ? xe - xs : 0;
+  const int Gs = use_global ? G : 0;
+  const int len = Gs + hh * ww;
+  if (t == 0 && threadIdx.x == 0) lens[s] = len;
+  const float* src = nullptr;
+  if (t < Gs) src = tokens + ((size_t)b * T + t) * D;
+  else if (t < len) {
+    const int r = t - Gs, y = ys + r / ww, xx = xs + r % ww;
+    src = tokens + ((size_t)b * T + G + y * n + xx) * D;
+  }
+  float4* dst = (float4*)(x + ((size_t)s * Tp + t) * D);
+  for (int c = threadIdx.x; c < D / 4; c += 256) dst[c] = src ? ((const float4*)src)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_box_seq_reduce(const float* __restrict__ x, const int32_t* __restrict__ lens, int Tp,
+                                                        int D, int Gs, int mode, float* __restrict__ out) {
+  const int s = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  const float* xs = x + (size_t)s * Tp * D + d;
+  if (mode == 0) { out[(size_t)s * D + d] = xs[0]; return; }
+  const int len = lens[s];
+  float acc = 0.f;
+  for (int t = Gs; t < len; ++t) acc += xs[(size_t)t * D];
+  out[(size_t)s * D + d] = acc / (float)(len - Gs);          // 0 / 0 = NaN for an empty region (torch.mean of no rows)
+}
+
+hipError_t launch_box_sequences(const float* tokens, const int32_t* slices, int s_base, int Ns, int NB, int T, int Tp, int G,
+                                int n, int D, int use_global, float* x, int32_t* lens, hipStream_t s) {
+  if (Ns < 1 || NB < 1 || D % 4 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_box_sequences, dim3(Tp, Ns), dim3(256), 0, s, tokens, slices, s_base, NB, T, Tp, G, n, D, use_global, x, lens);
+  return hipGetLastError();
+}
+
+hipError_t launch_box_seq_reduce(const float* x, const int32_t* lens, int Ns, int Tp, int D, int Gs, int mode, float* out,
+                                 hipStream_t s) {
+  if (Ns < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_box_seq_reduce, dim3(ceil_div(D, 256), Ns), dim3(256), 0, s, x, lens, Tp, D, Gs, mode, out);
+  return hipGetLastError();
+}
+
 }  // namespace pio

@@ -241,13 +241,24 @@ class Engine:
     def region_reduce(self, tokens: torch.Tensor, weights: torch.Tensor, img_index: Optional[torch.Tensor],
                       scale: float) -> torch.Tensor:
         """out[r] = scale * sum_p weights[r,p] * patch_tokens[img_index[r], p]"""
-        weights = weights.reshape(-1, self.n2).contiguous()
+        weights = self._dev(weights.reshape(-1, self.n2))
         R = weights.shape[0]
         idx = self._dev(img_index, torch.int32) if img_index is not None else None
         out = torch.empty(R, self.D, device=self.device, dtype=torch.float32)
         check(self.lib.pio_region_reduce(self.h, ptr(tokens), tokens.shape[0], ptr(weights), ptr(idx), R, float(scale),
                                          ptr(out), _stream()))
         return out
+
+    def bbox_double_dino(self, tokens: torch.Tensor, slices: torch.Tensor, use_cls: bool, return_type: str) -> torch.Tensor:
+        """extract_bboxes_feats_double_dino, return types "cls" / "avg" (P/src/bbox_utils.py:300-403): the last ViT block
+        re-run on [cls | registers | region patches] of every box.  ``slices`` int32 [B, NB, 4] = python-normalised
+        (y_start, y_end, x_start, x_end) patch-grid slices.  -> [B, NB, D]."""
+        B, NB = slices.shape[:2]
+        sl = self._dev(slices.reshape(-1, 4), torch.int32)
+        out = torch.empty(B * NB, self.D, device=self.device, dtype=torch.float32)
+        check(self.lib.pio_bbox_double_dino(self.h, ptr(tokens), ptr(sl), B, NB, 1 if use_cls else 0,
+                                            {"cls": 0, "avg": 1}[return_type], ptr(out), _stream()))
+        return out.view(B, NB, self.D)
 
     def gaussian_map(self, variance: float) -> torch.Tensor:
         m = torch.empty(self.n2, device=self.device, dtype=torch.float32)

@@ -282,8 +282,8 @@ class Patchioner(nn.Module):
                 ):
         assert clean_from in ["cls", "avg_self_attn"]
         assert cleaning_type in [None, "orthogonal_projection", "contrastive_mask"]
-        if double_DINO_for_bboxes:
-            raise NotImplementedError("double_DINO_for_bboxes (extract_bboxes_feats_double_dino) is a 'next' row")
+        if double_DINO_for_bboxes and double_DINO_for_bboxes_return_type not in ("cls", "avg", "gaussian_avg"):
+            raise ValueError("double_DINO_for_bboxes_return_type must be 'cls', 'avg' or 'gaussian_avg'")
         if cleaning_type is not None:
             raise NotImplementedError("ctx_cleaner paths are a 'next' row (SURVEY 8f.4)")
         if return_n_best_sims is not None:
@@ -338,8 +338,12 @@ class Patchioner(nn.Module):
         if bboxes is not None and not get_controllable_capts:
             bbox_bs = bs * bs_factor
             n_boxes = bboxes.shape[1]
-            bbox_feats = self._bbox_feats(tokens, bboxes, gaussian_avg, gaussian_bbox_variance, False,
-                                          self_attn if use_attn_map_for_bboxes else None).view(-1, embed_dim)
+            if double_DINO_for_bboxes:
+                bbox_feats = self._bbox_feats_double_dino(tokens, bboxes, double_DINO_use_cls, double_DINO_for_bboxes_return_type,
+                                                          gaussian_bbox_variance).view(-1, embed_dim)
+            else:
+                bbox_feats = self._bbox_feats(tokens, bboxes, gaussian_avg, gaussian_bbox_variance, False,
+                                              self_attn if use_attn_map_for_bboxes else None).view(-1, embed_dim)
             n_batch = math.ceil(bbox_feats.shape[0] / bbox_bs)
             outs['bbox_capts'] = []
             if compute_scores is True:
@@ -433,6 +437,38 @@ class Patchioner(nn.Module):
             return eng.region_reduce(tokens, single_map, None, 1.0)
         idx = torch.arange(B, dtype=torch.int32).repeat_interleave(NB)
         return eng.region_reduce(tokens, weights, idx, 1.0).view(B, NB, self.embed_dim)
+
+    def _bbox_feats_double_dino(self, tokens, bboxes, use_cls, return_type, variance):
+        """extract_bboxes_feats_double_dino (P/src/bbox_utils.py:300-403).  The reference floor-divides a CLONE of the
+        xywh tensor by the patch size and reads it as (x1, y1, x2, y2) with inclusive python slices; the last block runs
+        on [cls | registers | region patches] ("cls" / "avg": pio_bbox_double_dino); "gaussian_avg" weights the block's
+        INPUT patches with a gaussian normalised to sum 1 and never needs the block."""
+        if return_type == "cls" and not use_cls:
+            raise AssertionError("return_type 'cls' needs double_DINO_use_cls")       # reference: assert return_type != "cls"
+        idx = bboxes.clone()
+        idx //= self.patch_size
+        idx = idx.int().cpu()
+        B, NB = idx.shape[:2]
+        n = self.engine.n
+        slices = torch.zeros(B, NB, 4, dtype=torch.int32)
+        for i in range(B):
+            for j in range(NB):
+                x1, y1, x2, y2 = (int(v) for v in idx[i, j])
+                ys, ye, _ = slice(y1, y2 + 1).indices(n)
+                xs, xe, _ = slice(x1, x2 + 1).indices(n)
+                slices[i, j] = torch.tensor([ys, max(ye, ys), xs, max(xe, xs)])
+        if return_type != "gaussian_avg":
+            return self.engine.bbox_double_dino(tokens, slices, use_cls, return_type)
+        weights = torch.zeros(B * NB, n, n)
+        for r, (ys, ye, xs, xe) in enumerate(slices.view(-1, 4).tolist()):
+            h_span, w_span = ye - ys, xe - xs
+            if h_span == 0 or w_span == 0:
+                continue                                                              # empty region: sum of nothing = zeros
+            yc, xc = torch.meshgrid(torch.linspace(-1, 1, h_span), torch.linspace(-1, 1, w_span), indexing="ij")
+            w = torch.exp(-(xc ** 2 + yc ** 2) / variance)
+            weights[r, ys:ye, xs:xe] = w / w.sum()
+        img = torch.arange(B, dtype=torch.int32).repeat_interleave(NB)
+        return self.engine.region_reduce(tokens, weights.to(tokens.device), img, 1.0).view(B, NB, self.embed_dim)
 
     # ------------------------------------------------------------------------------------------
     def preprocess_images(self, images, no_crop: bool = False):

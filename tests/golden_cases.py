@@ -163,3 +163,12 @@ def prep_image(seed, w, h):
     base = 127.5 + 127.5 * np.sin(xx[..., None] / (3.0 + np.arange(3)) + yy[..., None] / (5.0 - np.arange(3)))
     img = base + rng.randint(-90, 91, size=(h, w, 3))
     return np.clip(img, 0, 255).astype(np.uint8)
+
+
+# ---- double-DINO boxes --------------------------------------------------------------------
+DDINO = dict(B=3, depth=2, seed_w=77, seed_tok=78, variance=0.5)
+
+
+def ddino_tokens():
+    """final (normed) tokens [B, 261, 768] fed to extract_bboxes_feats_double_dino: unit-scale like a LayerNorm output"""
+    return randn(DDINO["seed_tok"], DDINO["B"], 261, 768)

@@ -159,3 +159,37 @@ def test_grouped_decode_pipeline_matches_synchronous_forward():
     want = [m(imgs, get_cls_capt=True)["cls_capt"] for imgs, _ in batches]
     got = list(TraceCaptionPipeline(m, group_batches=4).run((imgs, None) for imgs, _ in batches))
     assert got == want
+
+
+def test_double_dino_boxes_vs_reference_golden(golden):
+    """extract_bboxes_feats_double_dino through pio_bbox_double_dino (last block re-run per box, fp16
+    operands) against the REFERENCE's outputs on the same seeded tokens / weights / boxes, every return type."""
+    from patchioner_amd import Patchioner
+    c = gc.DDINO
+    cfg = {"decap_weights": W.synth_decap(3), "prefix_size": 768, "linear_talk2dino": False, "support_memory_size": 0,
+           "dino_model": "dinov2_vitb14_reg", "normalize": True, "resize_dim": 224, "crop_dim": 224,
+           "dino_weights": W.synth_dinov2(c["seed_w"], "dinov2_vitb14_reg", depth=c["depth"]), "memory_bank": None,
+           "max_batch": 4}                                   # 15 sequences -> four chunks of <= 4
+    m = Patchioner.from_config(cfg, device="cuda")
+    g = golden("double_dino")
+    tokens = gc.ddino_tokens().cuda()
+    for name, boxes in (("regular", gc.boxes_regular()), ("dummies", gc.boxes_with_dummies())):
+        for use_cls in (True, False):
+            for rt in ("cls", "avg", "gaussian_avg"):
+                if rt == "cls" and not use_cls:
+                    continue
+                b = boxes.clone()
+                got = m._bbox_feats_double_dino(tokens, b, use_cls, rt, c["variance"]).cpu().numpy()
+                assert torch.equal(b, boxes)                # this path works on a clone: the caller's boxes survive
+                want = g["%s_%s_%s" % (name, "cls" if use_cls else "nocls", rt)]
+                assert np.array_equal(np.isnan(got), np.isnan(want)), (name, use_cls, rt)
+                ok = ~np.isnan(want)
+                tol = 2e-5 if rt == "gaussian_avg" else 4e-3 * np.abs(want[ok]).max()      # fp32 reduce / fp16 block
+                err = np.abs(got[ok] - want[ok]).max()
+                print("%s use_cls=%s %-12s max err %.2e (tol %.2e)" % (name, use_cls, rt, err, tol))
+                assert err <= tol, (name, use_cls, rt, err)
+    # routed through forward(): captions come back as [bs][n_boxes]
+    imgs = W.synth_images(7, 3, 224).cuda()
+    outs = m(imgs, get_cls_capt=False, bboxes=gc.boxes_regular(), double_DINO_for_bboxes=True,
+             double_DINO_for_bboxes_return_type="avg", double_DINO_use_cls=True)
+    assert len(outs["bbox_capts"]) == 3 and all(len(r) == 5 for r in outs["bbox_capts"])

@@ -303,6 +303,22 @@ def test_decoder_batch_sizes_and_graph_reuse(golden, eng224):
         assert np.array_equal(ids.cpu().numpy(), np.tile(want, (5, 1)))
 
 
+def test_decoder_nan_prefix_decodes_like_torch_argmax(golden, eng224):
+    """A prefix of NaNs (the reference's mean over an empty box region, bbox_utils.py:40-42 / 393) makes every logit NaN;
+    torch.argmax then returns index 0.  The GPU arg-max orders NaN like torch (and never indexes wte out of range);
+    the other rows of the batch are untouched."""
+    g = golden("decoder")
+    x = gc.decoder_prefixes("unit")[:5].clone()
+    x[1] = float("nan")
+    x[3, 100] = float("nan")
+    for reps in (1, 13):                        # 5 prefixes (1 row group) and 65 (4 row groups + a second chunk)
+        ids, _ = eng224.decode_greedy(x.repeat(reps, 1))
+        ids = ids.cpu().numpy().reshape(reps, 5, -1)
+        for r in range(reps):
+            assert (ids[r, 1] == 0).all() and (ids[r, 3] == 0).all()
+            assert np.array_equal(ids[r, [0, 2, 4]], g["unit_ids"][[0, 2, 4]])
+
+
 # ------------------------------------------------------------------------------------------- a14/a15
 def _make_model(with_bank, **over):
     from patchioner_amd import Patchioner
