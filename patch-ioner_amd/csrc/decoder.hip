@@ -277,6 +277,19 @@ __global__ __launch_bounds__(256) void k_dec_attention(const float* __restrict__
   float* kc = kcache + ((size_t)n * max_steps) * E + h * hd;
   float* vc = vcache + ((size_t)n * max_steps) * E + h * hd;
   const float scale = 1.0f / sqrtf((float)hd);
+  // The value rows this thread will weight do not depend on the scores: request them first, so that their latency
+  // runs beside the score pass instead of behind the soft-max (up to VPRE rows per thread; any further ones are
+  // loaded in the output loop).
+  const int nc4 = hd >> 2;                          // 48 float4 per head row
+  const int NJ = (256 / nc4) < 5 ? (256 / nc4) : 5;   // 5 key groups (240 threads active)
+  const int c4 = tid % nc4, jg = tid / nc4;
+  constexpr int VPRE = 7;
+  float4 vpre[VPRE];
+#pragma unroll
+  for (int i = 0; i < VPRE; ++i) {
+    const int j = jg + NJ * i;
+    vpre[i] = (jg < NJ && j <= pos) ? ((const float4*)(j == pos ? vn : vc + (size_t)j * E))[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   {
     const int seg = tid & 7, jl = tid >> 3, per4 = hd >> 5;   // hd/8 channels = per4 float4 (6 for 192)
     for (int j0 = 0; j0 <= pos; j0 += 32) {
@@ -299,19 +312,26 @@ __global__ __launch_bounds__(256) void k_dec_attention(const float* __restrict__
     vc[(size_t)pos * E + tid] = vn[tid];
   }
   __syncthreads();
-  float mx = -INFINITY;
-  for (int j = 0; j <= pos; ++j) mx = fmaxf(mx, s_sc[j]);
-  float den = 0.f;
-  for (int j = 0; j <= pos; ++j) den += expf(s_sc[j] - mx);
-  const float inv = 1.0f / den;
-  const int nc4 = hd >> 2;                          // 48 float4 per head row
-  const int NJ = (256 / nc4) < 5 ? (256 / nc4) : 5;   // 5 key groups (240 threads active)
-  const int c4 = tid % nc4, jg = tid / nc4;
+  if (tid < 64) {                                   // soft-max over the <= 64 scores once, by one wave (pos < 64)
+    const float sc = tid <= pos ? s_sc[tid] : -INFINITY;
+    const float mx = wave_max(sc);
+    const float e = tid <= pos ? expf(sc - mx) : 0.f;
+    const float inv = 1.0f / wave_sum(e);
+    s_sc[tid] = e * inv;
+  }
+  __syncthreads();
   if (jg < NJ) {
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-    for (int j = jg; j <= pos; j += NJ) {
-      const float p = expf(s_sc[j] - mx) * inv;
+#pragma unroll
+    for (int i = 0; i < VPRE; ++i) {
+      const int j = jg + NJ * i;
+      if (j <= pos) {
+        const float p = s_sc[j];
+        o.x += p * vpre[i].x; o.y += p * vpre[i].y; o.z += p * vpre[i].z; o.w += p * vpre[i].w;
+      }
+    }
+    for (int j = jg + NJ * VPRE; j <= pos; j += NJ) {
+      const float p = s_sc[j];
       const float4 v = ((const float4*)(j == pos ? vn : vc + (size_t)j * E))[c4];
       o.x += p * v.x; o.y += p * v.y; o.z += p * v.z; o.w += p * v.w;
     }
@@ -364,6 +384,8 @@ __global__ __launch_bounds__(256) void k_dec_select(const float* __restrict__ pa
   for (int w = 1; w < 4; ++w)
     if (arg_better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
   for (int d = tid; d < E; d += 256) x[(size_t)n * E + d] = wte[(size_t)bi * E + d] + wpe[(size_t)(step + 1) * E + d];
+  if (tid == 0) ids[(size_t)n * steps + step] = bi;
+  if (logprob == nullptr) return;                   // block-uniform: the log-probability pass is only run on request
   {
     float se = 0.f;
 #pragma unroll
@@ -372,10 +394,7 @@ __global__ __launch_bounds__(256) void k_dec_select(const float* __restrict__ pa
     if (lane == 0) s_s[wid] = se;
   }
   __syncthreads();
-  if (tid == 0) {
-    ids[(size_t)n * steps + step] = bi;
-    if (logprob != nullptr) logprob[(size_t)n * steps + step] = -logf((s_s[0] + s_s[1]) + (s_s[2] + s_s[3]));
-  }
+  if (tid == 0) logprob[(size_t)n * steps + step] = -logf((s_s[0] + s_s[1]) + (s_s[2] + s_s[3]));
 }
 
 template <int CPW, int KS, int EPI, int LN>
