@@ -467,7 +467,8 @@ int pio_create(const pio_config* cfg, pio_handle* out) {
     return fail(PIO_ERR_INVALID_ARG, "pio_create: crop_dim must be a multiple of patch_size");
   if (cfg->max_batch < 1 || cfg->max_prefixes < 1 || cfg->max_prefixes > 64 || cfg->max_steps < 1 || cfg->max_steps > 64)
     return fail(PIO_ERR_INVALID_ARG, "pio_create: capacities out of range (prefixes <= 64, steps <= 64)");
-  if (cfg->readout_heads != 16) return fail(PIO_ERR_INVALID_ARG, "pio_create: readout_heads must be 16");
+  if (cfg->readout_heads != 16 && cfg->readout_heads * 64 != cfg->embed_dim)
+    return fail(PIO_ERR_INVALID_ARG, "pio_create: readout_heads must be 16, or embed_dim / 64 (ViT-S: 6)");
   int ndev = 0;
   HIP_OK(hipGetDeviceCount(&ndev));
   if (cfg->device < 0 || cfg->device >= ndev) return fail(PIO_ERR_INVALID_ARG, "pio_create: no such HIP device");

@@ -421,6 +421,7 @@ static hipError_t dec_gemm(const float* W, const float* X, int N, int Nout, int 
   if (N < 1 || N > 64) return hipErrorInvalidValue;
   if (K == 768) return dec_gemm_rg<12, 1, EPI, LN>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);
   if (K == 512) return dec_gemm_rg<8, 1, EPI, LN>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);
+  if (K == 384) return dec_gemm_rg<6, 1, EPI, LN>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);   // ViT-S prefix
   if (K == 3072 && EPI == DE_RESID && !LN && ws != nullptr && cnt != nullptr && Nout <= 16 * DEC_MAX_COLGROUPS)
     return dec_gemm_rg<12, 4, DE_RESID, 0>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);
   return hipErrorInvalidValue;

@@ -26,6 +26,18 @@ __global__ __launch_bounds__(256) void k_cls_logits(const float* __restrict__ qk
   const int per = D >> 6;
   const float* q = qkv + (size_t)b * T * 3 * D;                      // CLS row, q part
   const float* k = qkv + ((size_t)b * T + G + p) * 3 * D + D;        // patch row, k part
+  if (Hr * 64 == D) {
+    // ViT-S read-out: 6 heads x 64 channels (P/src/model.py:336).  Lane l takes channel l of every head, so head i
+    // is one wave reduction.
+    float tot = 0.f;
+    for (int i = 0; i < Hr; ++i) {
+      const float hs = wave_sum((q[64 * i + lane] * scale) * k[64 * i + lane]);
+      if (head_logits != nullptr && lane == 0) head_logits[((size_t)b * Hr + i) * n2 + p] = hs;
+      tot += hs;
+    }
+    if (lane == 0) mean_logits[(size_t)b * n2 + p] = tot / (float)Hr;
+    return;
+  }
   float part = 0.f;
   for (int i = 0; i < per; ++i) {
     const int d = lane * per + i;
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(256) void k_gaussian_map(int n, float variance, flo
 hipError_t launch_cls_logits(const float* qkv_last, int B, int T, int G, int D, int Hr, float scale,
                              float* mean_logits, float* head_logits, hipStream_t s) {
   const int n2 = T - G;
-  if (D % 64 != 0 || Hr != 16) return hipErrorInvalidValue;
+  if (D % 64 != 0 || (Hr != 16 && Hr * 64 != D)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_cls_logits, dim3(ceil_div(B * n2, 4)), dim3(256), 0, s, qkv_last, B, T, G, D, Hr, scale,
                      mean_logits, head_logits);
   return hipGetLastError();

@@ -128,8 +128,6 @@ class Patchioner(nn.Module):
         self.num_tokens = self.num_global_tokens + self.num_patch_tokens
         self.embed_dim, depth, heads = W.dino_arch(dino_model)
         self.num_attn_heads = 16 if 'vits' not in dino_model else 6
-        if self.num_attn_heads != 16:
-            raise NotImplementedError("ViT-S read-out uses 6 heads in the reference; not built yet")
         self.scale = 0.125
         self.patch_size = patch_size
         self.backbone_type = 'DINO'
@@ -171,7 +169,7 @@ class Patchioner(nn.Module):
                              num_registers=self.num_global_tokens - 1, crop_dim=crop_dim, patch_size=patch_size,
                              pretrain_grid=int(math.isqrt(vit_sd["pos_embed"].shape[1] - 1)), prefix_size=prefix_size,
                              max_batch=max_batch, max_prefixes=max_prefixes, vit_dtype=vit_dtype,
-                             device_index=self._device.index)
+                             device_index=self._device.index, readout_heads=self.num_attn_heads, readout_scale=self.scale)
         self.engine.load_state_dict(vit_sd)
         self.engine.load_state_dict(dec_sd)            # strict=False like the reference (decap.py:214)
         if inv_sd:

@@ -172,3 +172,13 @@ DDINO = dict(B=3, depth=2, seed_w=77, seed_tok=78, variance=0.5)
 def ddino_tokens():
     """final (normed) tokens [B, 261, 768] fed to extract_bboxes_feats_double_dino: unit-scale like a LayerNorm output"""
     return randn(DDINO["seed_tok"], DDINO["B"], 261, 768)
+
+
+# ---- ViT-S read-out: 6 heads of 64 channels (P/src/model.py:336) -------------------------------------------
+ATTN_VITS = dict(B=2, n=16, D=384, heads=6, scale=0.125, G=5, seed_qkv=13, seed_patch=14)
+
+
+def attn_vits_inputs():
+    c = ATTN_VITS
+    T = c["G"] + c["n"] ** 2
+    return randn(c["seed_qkv"], c["B"], T, 3 * c["D"]), randn(c["seed_patch"], c["B"], c["n"] ** 2, c["D"])

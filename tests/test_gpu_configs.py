@@ -193,3 +193,51 @@ def test_double_dino_boxes_vs_reference_golden(golden):
     outs = m(imgs, get_cls_capt=False, bboxes=gc.boxes_regular(), double_DINO_for_bboxes=True,
              double_DINO_for_bboxes_return_type="avg", double_DINO_use_cls=True)
     assert len(outs["bbox_capts"]) == 3 and all(len(r) == 5 for r in outs["bbox_capts"])
+
+
+def test_vits14_backbone_readout_and_captions(O, golden):
+    """dinov2_vits14_reg (D = 384, 6 heads; the reference then reads the CLS attention out with 6 heads x 64 channels,
+    model.py:336): read-out kernels vs the reference's golden outputs, backbone vs the oracle, and the whole DeCap path
+    (384-wide memory bank and decoder prefix) vs the oracle's captions."""
+    from patchioner_amd import Patchioner
+    from patchioner_amd.engine import Engine
+    from patchioner_amd.tokenizer import ClipDetokenizer
+    c = gc.ATTN_VITS
+    g = golden("attn_readout_vits")
+    e = Engine(embed_dim=384, depth=1, num_heads=6, num_registers=4, crop_dim=224, max_batch=2, vit_dtype="fp16",
+               readout_heads=6, prefix_size=384)
+    try:
+        e.load_state_dict(W.synth_dinov2(30, "dinov2_vits14_reg", depth=1))
+        e.finalize()
+        qkv, patches = gc.attn_vits_inputs()
+        tokens = torch.cat([torch.zeros(c["B"], c["G"], c["D"]), patches], 1).cuda()
+        sa, maps, avg, dis = e.cls_attention(qkv.cuda(), tokens, want_maps=True, want_avg=True, want_disentangled=True)
+        np.testing.assert_allclose(sa.cpu().numpy(), g["self_attn"], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(maps.cpu().numpy(), g["maps"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(avg.cpu().numpy(), g["avg_self_attn_token"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(dis.cpu().numpy(), g["disentangled"], rtol=1e-4, atol=1e-6)
+    finally:
+        e.close()
+    sd = W.synth_dinov2(31, "dinov2_vits14_reg", depth=2)
+    dec = W.synth_decap(5, prefix_size=384)
+    bank = W.synth_bank(62, 1024, 384)
+    cfg = {"decap_weights": dec, "prefix_size": 384, "linear_talk2dino": False, "support_memory_size": 1024,
+           "dino_model": "dinov2_vits14_reg", "normalize": True, "resize_dim": 224, "crop_dim": 224, "dino_weights": sd,
+           "memory_bank": bank, "max_batch": 4}
+    m = Patchioner.from_config(cfg, device="cuda")
+    assert m.embed_dim == 384 and m.num_attn_heads == 6
+    imgs = W.synth_images(41, 3, 224)
+    tokens, qkv = m.engine.vit_forward(imgs)
+    vit = O.DinoV2Oracle(sd, num_heads=6)
+    d = vit(imgs)
+    ref = torch.cat([d["x_norm_clstoken"][:, None], d["x_norm_regtokens"], d["x_norm_patchtokens"]], 1)
+    err = (tokens.cpu() - ref).abs().max() / ref.abs().max()
+    print("vit-S rel-max-err %.2e" % err)
+    assert err <= 4e-3
+    orc = O.PatchionerOracle(vit, O.DeCapOracle(dec), bank, ClipDetokenizer().decode, crop_dim=224, num_attn_heads=6)
+    kw = dict(get_cls_capt=True, get_avg_self_attn_capt=True, traces=[gc.block_trace(3, 4), gc.block_trace(9, 2), gc.block_trace(0, 12)])
+    got, want = m(imgs.cuda(), **kw), orc.forward(imgs.clone(), **kw)
+    same = sum(a == b for k in want for a, b in zip(got[k], want[k]))
+    total = sum(len(want[k]) for k in want)
+    print("vit-S captions: %d / %d identical to the oracle" % (same, total))
+    assert set(got) == set(want) and same >= total - 1
