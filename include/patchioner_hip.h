@@ -196,6 +196,14 @@ int pio_profile_read(pio_handle h, int32_t cls, double* total_ms, int64_t* launc
 int pio_bbox_double_dino(pio_handle h, const float* tokens, const int32_t* slices, int32_t B, int32_t NB, int32_t use_cls,
                          int32_t return_type, float* out, pio_stream stream);
 
+/* -- f.4: Patchioner.ctx_cleaner (P/src/model.py:1425-1436, used by forward(cleaning_type=...) at model.py:879-922):
+ *    dirty [R][D], row r cleaned with context row r / rows_per_ctx of ctx; cleaning_type 0 = "orthogonal_projection"
+ *    (dirty - alpha * (dirty . ctx / |ctx|^2) * ctx), 1 = "contrastive_mask" (dirty * (1 - ctx / (|ctx| + 1e-6))).
+ *    normalize_inputs: both are L2-normalised first (the clean_after_projection=False branch, model.py:907-913).
+ *    out may alias dirty.  D <= 1024. -- */
+int pio_ctx_clean(pio_handle h, const float* dirty, const float* ctx, int32_t R, int32_t D, int32_t rows_per_ctx,
+                  int32_t cleaning_type, float alpha, int32_t normalize_inputs, float* out, pio_stream stream);
+
 /* -- a0: model.image_transforms / image_transforms_no_crop on the device (P/src/model.py:347-357):
  *    T.Resize(resize_dim, BICUBIC) -> T.CenterCrop(crop_dim) -> T.ToTensor() -> T.Normalize(ImageNet mean / std)
  *    (mode 0), or T.Resize((resize_dim, resize_dim), BICUBIC) -> ToTensor -> Normalize (mode 1; crop_dim ignored),

@@ -319,6 +319,18 @@ def project(image_embedding: torch.Tensor, bank: torch.Tensor, temperature: floa
     return out
 
 
+def ctx_cleaner(dirty_embeds: torch.Tensor, ctx_embed: torch.Tensor, cleaning_type="orthogonal_projection", alpha=1.0,
+                epsilon=1e-6):
+    """P/src/model.py:1425-1436: remove the context direction from [B, S, D] embeddings (ctx_embed [B, D])."""
+    ctx = ctx_embed.unsqueeze(1)
+    if cleaning_type == "orthogonal_projection":
+        projection = (dirty_embeds @ ctx.transpose(-1, -2)) / (torch.norm(ctx, dim=-1, keepdim=True) ** 2)
+        return dirty_embeds - alpha * projection * ctx
+    if cleaning_type == "contrastive_mask":
+        return dirty_embeds * (1 - (ctx / (torch.norm(ctx, p=2, dim=2, keepdim=True) + epsilon)))
+    return None
+
+
 def get_pseudo_inverse(A: torch.Tensor) -> torch.Tensor:
     """P/src/embedding_utils.py:3-15."""
     U, S, Vh = torch.linalg.svd(A, full_matrices=False)
@@ -460,7 +472,8 @@ class PatchionerOracle:
                 get_patch_capts=False, get_register_capts=False, bboxes=None, traces=None,
                 get_controllable_capts=False, bs_factor=4, gaussian_avg=False, gaussian_bbox_variance=0.5,
                 get_avg_patch_capt=False, gaussian_img_variance=1, use_attn_map_for_bboxes=False,
-                use_attention_tracing=False, compute_scores=False):
+                use_attention_tracing=False, compute_scores=False, cleaning_type=None, clean_after_projection=True,
+                alpha=1.0, clean_from="cls"):
         outs = {}
         bs = imgs.shape[0]
         d = self.vit(imgs)
@@ -468,6 +481,21 @@ class PatchionerOracle:
         self_attn, maps = process_self_attention(self.vit.last_qkv, bs, self.num_tokens, self.num_attn_heads,
                                                  self.embed_dim, self.scale, self.num_global_tokens)
         avg_tok, disentangled = attention_weighted_means(self_attn, maps, patches)
+        if cleaning_type is not None:
+            # P/src/model.py:879-922.  project() normalises its argument IN PLACE: with clean_after_projection the
+            # patch tokens and the clean-from token of the backbone output are left L2-normalised.
+            cf = d["x_norm_clstoken"] if clean_from == "cls" else avg_tok
+            cleaned = []
+            for i in range(bs):
+                p_i, c_i = patches[i:i + 1], cf[i:i + 1]
+                if clean_after_projection:
+                    cleaned.append(ctx_cleaner(project(p_i, self.bank, normalize=True), project(c_i, self.bank, normalize=True),
+                                               cleaning_type=cleaning_type, alpha=alpha))
+                else:
+                    cleaned.append(project(ctx_cleaner(p_i / p_i.norm(dim=-1, keepdim=True), c_i / c_i.norm(dim=-1, keepdim=True),
+                                                       cleaning_type=cleaning_type, alpha=alpha), self.bank, normalize=True))
+            patches = torch.cat(cleaned, dim=0)
+        noproj = cleaning_type is not None            # patch / box captions skip the projection after cleaning
         D = patches.shape[-1]
 
         def put(key, ret):
@@ -484,8 +512,8 @@ class PatchionerOracle:
             put("avg_patch_capt", self.caption_tokens(compute_region_means(patches, gaussian_img_variance),
                                                       compute_scores=compute_scores))
         # P/src/model.py:946-975: nested per-image lists of 16 head / n*n patch / 4 register captions
-        def nested(key, score_key, toks, per):
-            ret = self.caption_tokens(toks, compute_scores=compute_scores)
+        def nested(key, score_key, toks, per, project_flag=True):
+            ret = self.caption_tokens(toks, project_flag=project_flag, compute_scores=compute_scores)
             caps = ret[0] if compute_scores else ret
             outs[key] = [caps[i * per:(i + 1) * per] for i in range(bs)]
             if compute_scores:
@@ -494,7 +522,7 @@ class PatchionerOracle:
         if get_attn_heads_capt:
             nested("attn_heads_capts", "attn_heads_scores", disentangled.reshape(-1, D), self.num_attn_heads)
         if get_patch_capts:
-            nested("patch_tokens_capts", "patch_tokens_scores", patches.reshape(-1, D), patches.shape[1])
+            nested("patch_tokens_capts", "patch_tokens_scores", patches.reshape(-1, D), patches.shape[1], project_flag=not noproj)
         if get_register_capts:
             nested("register_capts", "register_scores", d["x_norm_regtokens"].reshape(-1, D), 4)
         if bboxes is not None and not get_controllable_capts:
@@ -509,7 +537,7 @@ class PatchionerOracle:
             for i in range(n_batch):
                 s = i * bbox_bs
                 e = s + bbox_bs if i < n_batch - 1 else feats.shape[0]
-                ret = self.caption_tokens(feats[s:e], compute_scores=compute_scores)
+                ret = self.caption_tokens(feats[s:e], project_flag=not noproj, compute_scores=compute_scores)
                 if compute_scores:
                     caps.extend(ret[0]); scores.extend(ret[1])
                 else:

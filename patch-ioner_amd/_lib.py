@@ -66,6 +66,8 @@ SIGNATURES = {
     "pio_profile_read": (c_int32, [c_void_p, c_int32, POINTER(c_double), POINTER(c_int64), POINTER(c_double),
                                    POINTER(c_double)]),
     "pio_bbox_double_dino": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "pio_ctx_clean": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, c_void_p,
+                                c_void_p]),
     "pio_preprocess": (c_int32, [c_void_p, c_void_p, POINTER(c_int64), POINTER(c_int32), c_int32, c_int32, c_int32, c_int32,
                                  c_void_p, c_void_p]),
     "pio_num_tokens": (c_int32, [c_void_p]),

@@ -867,6 +867,18 @@ int pio_profile_read(pio_handle c, int32_t cls, double* total_ms, int64_t* launc
   return PIO_OK;
 }
 
+int pio_ctx_clean(pio_handle c, const float* dirty, const float* ctx, int32_t R, int32_t D, int32_t rows_per_ctx,
+                  int32_t cleaning_type, float alpha, int32_t normalize_inputs, float* out, pio_stream stream) {
+  if (!c || !dirty || !ctx || !out) return fail(PIO_ERR_INVALID_ARG, "pio_ctx_clean: null argument");
+  if (R < 1 || D < 1 || rows_per_ctx < 1) return fail(PIO_ERR_INVALID_ARG, "pio_ctx_clean: empty input");
+  if (cleaning_type < 0 || cleaning_type > 1)
+    return fail(PIO_ERR_INVALID_ARG, "pio_ctx_clean: cleaning_type 0 (orthogonal_projection) or 1 (contrastive_mask)");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  if (D > 1024) return fail(PIO_ERR_SHAPE, "pio_ctx_clean: D above 1024");
+  HIP_OK(launch_ctx_clean(dirty, ctx, R, D, rows_per_ctx, cleaning_type, alpha, normalize_inputs, out, (hipStream_t)stream));
+  return PIO_OK;
+}
+
 int pio_preprocess(pio_handle c, const void* pixels, const int64_t* offsets, const int32_t* wh, int32_t B,
                    int32_t resize_dim, int32_t crop_dim, int32_t mode, float* out, void* stream) {
   if (!c || !pixels || !offsets || !wh || !out || B < 1 || resize_dim < 1 || (mode == 0 && crop_dim < 1) || mode < 0 || mode > 1)

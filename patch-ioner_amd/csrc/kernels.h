@@ -74,6 +74,8 @@ hipError_t launch_bbox_weights(const int32_t* boxes, int B, int NB, int n, int m
                                float* single, hipStream_t s);
 hipError_t launch_region_reduce(const float* tokens, int T, int G, int D, int n2, const float* weights,
                                 const int32_t* img_index, int R, float scale, float* out, hipStream_t s);
+hipError_t launch_ctx_clean(const float* dirty, const float* ctx, int R, int D, int rows_per_ctx, int mode, float alpha,
+                            int normalize_inputs, float* out, hipStream_t s);
 hipError_t launch_gaussian_map(int n, float variance, float* map, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------

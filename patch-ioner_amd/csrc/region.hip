@@ -292,4 +292,57 @@ hipError_t launch_gaussian_map(int n, float variance, float* map, hipStream_t s)
   return hipGetLastError();
 }
 
+
+// ctx_cleaner (P/src/model.py:1425-1436): row r of `dirty` [R][D] belongs to context row r / rows_per_ctx of `ctx`.
+//   mode 0 orthogonal_projection: out = dirty - alpha * (dirty . ctx / |ctx|^2) * ctx
+//   mode 1 contrastive_mask     : out = dirty * (1 - ctx / (|ctx| + 1e-6))
+//   normalize_inputs: dirty and ctx are L2-normalised first (the reference's clean_after_projection=False branch,
+//   model.py:907-913).  One wave per row, the row in registers (D <= 1024); in place when out == dirty.
+__global__ __launch_bounds__(256) void k_ctx_clean(const float* __restrict__ dirty, const float* __restrict__ ctx, int R, int D,
+                                                   int rows_per_ctx, int mode, float alpha, int normalize_inputs, float* out) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* dp = dirty + (size_t)r * D;
+  const float* cp = ctx + (size_t)(r / rows_per_ctx) * D;
+  float d[16], c[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = lane + 64 * i;
+    d[i] = k < D ? dp[k] : 0.f;
+    c[i] = k < D ? cp[k] : 0.f;
+  }
+  if (normalize_inputs) {
+    float nd = 0.f, nc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { nd += d[i] * d[i]; nc += c[i] * c[i]; }
+    nd = sqrtf(wave_sum(nd));
+    nc = sqrtf(wave_sum(nc));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { d[i] = d[i] / nd; c[i] = c[i] / nc; }
+  }
+  float dot = 0.f, nn = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dot += d[i] * c[i]; nn += c[i] * c[i]; }
+  dot = wave_sum(dot);
+  nn = wave_sum(nn);
+  float* o = out + (size_t)r * D;
+  const float nrm = sqrtf(nn);
+  const float proj = dot / (nrm * nrm);              // torch.norm(ctx) ** 2, as the reference writes it
+  const float den = nrm + 1e-6f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = lane + 64 * i;
+    if (k < D) o[k] = mode == 0 ? d[i] - alpha * proj * c[i] : d[i] * (1.0f - c[i] / den);
+  }
+}
+
+hipError_t launch_ctx_clean(const float* dirty, const float* ctx, int R, int D, int rows_per_ctx, int mode, float alpha,
+                            int normalize_inputs, float* out, hipStream_t s) {
+  if (R < 1 || D < 1 || D > 1024 || rows_per_ctx < 1 || mode < 0 || mode > 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_ctx_clean, dim3(ceil_div(R, 4)), dim3(256), 0, s, dirty, ctx, R, D, rows_per_ctx, mode, alpha,
+                     normalize_inputs, out);
+  return hipGetLastError();
+}
+
 }  // namespace pio

@@ -260,6 +260,27 @@ class Engine:
                                             {"cls": 0, "avg": 1}[return_type], ptr(out), _stream()))
         return out.view(B, NB, self.D)
 
+    def ctx_clean(self, dirty: torch.Tensor, ctx: torch.Tensor, cleaning_type: str, alpha: float,
+                  normalize_inputs: bool = False) -> torch.Tensor:
+        """Patchioner.ctx_cleaner (P/src/model.py:1425-1436): dirty [B, S, D], ctx [B, D] -> cleaned [B, S, D];
+        ``normalize_inputs`` L2-normalises both first (model.py:907-913)."""
+        dirty, ctx = self._dev(dirty), self._dev(ctx)
+        B, S, D = dirty.shape
+        out = torch.empty_like(dirty)
+        check(self.lib.pio_ctx_clean(self.h, ptr(dirty), ptr(ctx), B * S, D, S,
+                                     {"orthogonal_projection": 0, "contrastive_mask": 1}[cleaning_type], float(alpha),
+                                     1 if normalize_inputs else 0, ptr(out), _stream()))
+        return out
+
+    def project_many(self, q: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        """project() for any number of queries [N, D] (in-place L2 normalisation of q, like project): chunks of
+        max_prefixes rows, one pass over the bank per 16 of them."""
+        assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous()
+        out = torch.empty_like(q)
+        for s in range(0, q.shape[0], self.max_prefixes):
+            out[s:s + self.max_prefixes] = self.project(q[s:s + self.max_prefixes], normalize=normalize)
+        return out
+
     def gaussian_map(self, variance: float) -> torch.Tensor:
         m = torch.empty(self.n2, device=self.device, dtype=torch.float32)
         check(self.lib.pio_gaussian_map(self.h, float(variance), ptr(m), _stream()))

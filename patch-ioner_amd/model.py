@@ -282,8 +282,9 @@ class Patchioner(nn.Module):
         assert cleaning_type in [None, "orthogonal_projection", "contrastive_mask"]
         if double_DINO_for_bboxes and double_DINO_for_bboxes_return_type not in ("cls", "avg", "gaussian_avg"):
             raise ValueError("double_DINO_for_bboxes_return_type must be 'cls', 'avg' or 'gaussian_avg'")
-        if cleaning_type is not None:
-            raise NotImplementedError("ctx_cleaner paths are a 'next' row (SURVEY 8f.4)")
+        if cleaning_type is not None and self.im_proj is None:
+            # the reference calls self.im_proj.project unconditionally here (model.py:900-913)
+            raise AttributeError("cleaning_type needs the memory-bank projector (support_memory_size > 0)")
         if return_n_best_sims is not None:
             raise NotImplementedError("return_n_best_sims is only usable with calculate_argmax_text in the reference")
         if caption_bboxes_type is not None:
@@ -295,8 +296,26 @@ class Patchioner(nn.Module):
         tokens, qkv = eng.vit_forward(imgs, want_qkv=True)
         G = self.num_global_tokens
         embed_dim = self.embed_dim
+        clean_avg = cleaning_type is not None and clean_from == "avg_self_attn"
         self_attn, _, avg_self_attn_token, disentangled_self_attn = eng.cls_attention(
-            qkv, tokens, want_maps=False, want_avg=get_avg_self_attn_capt, want_disentangled=get_attn_heads_capt)
+            qkv, tokens, want_maps=False, want_avg=get_avg_self_attn_capt or clean_avg, want_disentangled=get_attn_heads_capt)
+        if cleaning_type is not None:
+            # P/src/model.py:879-922: every patch token goes through the memory-bank projection and ctx_cleaner (before
+            # or after it); the cleaned, projected tokens REPLACE x_norm_patchtokens, and the patch / box captions
+            # below skip their own projection.  (The reference's in-place normalisation of the tokens it hands to
+            # project() is invisible afterwards: every later consumer projects, i.e. re-normalises, or uses the
+            # replaced patch tokens.)
+            n2 = self.num_patch_tokens
+            patches = tokens[:, G:].contiguous()
+            cf = avg_self_attn_token if clean_avg else tokens[:, 0].contiguous()
+            if clean_after_projection:
+                proj = eng.project_many(patches.view(-1, embed_dim), normalize=True).view(bs, n2, embed_dim)
+                cleaned = eng.ctx_clean(proj, eng.project_many(cf.clone(), normalize=True), cleaning_type, alpha)
+            else:
+                cleaned = eng.ctx_clean(patches, cf, cleaning_type, alpha, normalize_inputs=True)
+                cleaned = eng.project_many(cleaned.view(-1, embed_dim), normalize=True).view(bs, n2, embed_dim)
+            tokens = torch.cat([tokens[:, :G], cleaned], dim=1)
+        project_regions = cleaning_type is None
 
         def put(key, score_key, ret):
             if compute_scores is True:
@@ -321,7 +340,7 @@ class Patchioner(nn.Module):
                 outs['attn_heads_scores'] = [ret[1][i * H:(i + 1) * H] for i in range(bs)]
         if get_patch_capts:
             n_patches = self.num_patch_tokens
-            ret = self.caption_tokens(tokens[:, G:].reshape(-1, embed_dim), project=True, compute_scores=compute_scores)
+            ret = self.caption_tokens(tokens[:, G:].reshape(-1, embed_dim), project=project_regions, compute_scores=compute_scores)
             caps = ret[0] if compute_scores is True else ret
             outs['patch_tokens_capts'] = [caps[i * n_patches:(i + 1) * n_patches] for i in range(bs)]
             if compute_scores is True:
@@ -349,7 +368,7 @@ class Patchioner(nn.Module):
             for i in range(n_batch):
                 start = i * bbox_bs
                 end = start + bbox_bs if i < n_batch - 1 else bbox_feats.shape[0]
-                ret = self.caption_tokens(bbox_feats[start:end], project=True, compute_scores=compute_scores)
+                ret = self.caption_tokens(bbox_feats[start:end], project=project_regions, compute_scores=compute_scores)
                 if compute_scores is True:
                     outs['bbox_capts'].extend(ret[0])
                     outs['bbox_scores'].extend(ret[1])

@@ -182,3 +182,12 @@ def attn_vits_inputs():
     c = ATTN_VITS
     T = c["G"] + c["n"] ** 2
     return randn(c["seed_qkv"], c["B"], T, 3 * c["D"]), randn(c["seed_patch"], c["B"], c["n"] ** 2, c["D"])
+
+
+# ---- ctx_cleaner (P/src/model.py:1425-1436) ----------------------------------------------------------------
+CTX = dict(B=3, S=9, D=96, seed=31)
+
+
+def ctx_inputs():
+    c = CTX
+    return randn(c["seed"], c["B"], c["S"], c["D"]), randn(c["seed"] + 1, c["B"], c["D"])

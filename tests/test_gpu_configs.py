@@ -241,3 +241,37 @@ def test_vits14_backbone_readout_and_captions(O, golden):
     total = sum(len(want[k]) for k in want)
     print("vit-S captions: %d / %d identical to the oracle" % (same, total))
     assert set(got) == set(want) and same >= total - 1
+
+
+def test_ctx_cleaner_kernel_and_forward(O, golden):
+    """Patchioner.ctx_cleaner on the GPU vs the reference's golden outputs, and forward(cleaning_type=...)
+    (all patch tokens projected through the bank, cleaned before / after the projection, box captions without a second
+    projection) vs the oracle."""
+    from patchioner_amd.engine import Engine
+    g = golden("ctx_cleaner")
+    dirty, ctx = gc.ctx_inputs()
+    e = Engine(embed_dim=768, depth=1, num_heads=12, num_registers=4, crop_dim=224, max_batch=2, vit_dtype="fp16")
+    try:
+        for ct in ("orthogonal_projection", "contrastive_mask"):
+            for alpha in (1.0, 0.35):
+                got = e.ctx_clean(dirty, ctx, ct, alpha).cpu().numpy()
+                np.testing.assert_allclose(got, g["%s_%g" % (ct, alpha)], rtol=1e-5, atol=1e-6)
+            dn, cn = dirty / dirty.norm(dim=-1, keepdim=True), ctx / ctx.norm(dim=-1, keepdim=True)
+            np.testing.assert_allclose(e.ctx_clean(dirty, ctx, ct, 0.7, normalize_inputs=True).cpu().numpy(),
+                                       O.ctx_cleaner(dn, cn, cleaning_type=ct, alpha=0.7).numpy(), rtol=1e-5, atol=1e-6)
+    finally:
+        e.close()
+    m = _model(224, True, max_batch=2)
+    orc = _oracle_for(O, 224, True)
+    imgs = W.synth_images(17, 2, 224)
+    boxes = gc.boxes_regular()[:2, :4]
+    for ct, after, cf in (("orthogonal_projection", True, "cls"), ("contrastive_mask", False, "avg_self_attn")):
+        kw = dict(get_cls_capt=True, bboxes=None, cleaning_type=ct, clean_after_projection=after, alpha=0.8, clean_from=cf,
+                  gaussian_avg=True, gaussian_bbox_variance=0.5)
+        got = m(imgs.cuda(), **{**kw, "bboxes": boxes.clone()})
+        want = orc.forward(imgs.clone(), **{**kw, "bboxes": boxes.clone()})
+        flat_g = got["cls_capt"] + sum(got["bbox_capts"], [])
+        flat_w = want["cls_capt"] + sum(want["bbox_capts"], [])
+        same = sum(a == b for a, b in zip(flat_g, flat_w))
+        print("cleaning %s after=%s from=%s: %d / %d captions identical to the oracle" % (ct, after, cf, same, len(flat_w)))
+        assert len(flat_g) == len(flat_w) == 10 and same >= 9
