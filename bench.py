@@ -168,6 +168,7 @@ def main():
     dt = time.perf_counter() - t0
     # The reference's own call pattern: one synchronous forward at a time (no pipelining).
     sync_steps = min(args.steps, 15)
+    step()                                  # untimed: the 16-prefix decode graph is captured on its first call
     fence()
     ts = time.perf_counter()
     for _ in range(sync_steps):

@@ -275,3 +275,25 @@ def test_ctx_cleaner_kernel_and_forward(O, golden):
         same = sum(a == b for a, b in zip(flat_g, flat_w))
         print("cleaning %s after=%s from=%s: %d / %d captions identical to the oracle" % (ct, after, cf, same, len(flat_w)))
         assert len(flat_g) == len(flat_w) == 10 and same >= 9
+
+
+def test_pipeline_soak_is_deterministic():
+    """300 batches of the same input through the grouped-decode pipeline (staging rings, two streams, graph replays,
+    hand-counted asynchronous loads in the LM head): every group's token ids equal the first group's."""
+    from patchioner_amd.pipeline import TraceCaptionPipeline
+    m = _model(224, True, max_batch=16)
+    imgs = W.synth_images(55, 16, 224).cuda()
+    traces = [gc.block_trace(i % 13, (3 * i) % 13) for i in range(16)]
+    pipe = TraceCaptionPipeline(m, group_batches=4)
+    first, seen, groups = None, None, 0
+    for _ in pipe.run((imgs, traces) for _ in range(300)):
+        if pipe.last_ids is not seen:
+            seen = pipe.last_ids
+            ids = seen.cpu()
+            groups += 1
+            if first is None:
+                first = ids
+                assert torch.equal(ids[:16], ids[16:32]) and torch.equal(ids[:16], ids[48:64])
+            else:
+                assert torch.equal(ids, first), "group %d differs" % groups
+    assert groups == 75
