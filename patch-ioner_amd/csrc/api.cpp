@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -94,6 +95,8 @@ struct pio_context {
   // decoder weights
   float *clip_w = nullptr, *clip_b = nullptr, *wte = nullptr, *wpe = nullptr, *head_w = nullptr, *head_c = nullptr,
         *head_d = nullptr;
+  uint16_t* head_w16 = nullptr; float head_w16_unscale = 1.f, head_bound_coef = 0.f;   // fp16 arg-max filter of the LM head
+  void* dec_xh = nullptr; float* lm_stats = nullptr; float* lm_gmax = nullptr;
   std::vector<DecLayerW> dl;
   // decoder workspaces
   float *dx = nullptr, *dqkv = nullptr, *datt = nullptr, *dhid = nullptr, *kcache = nullptr,
@@ -306,6 +309,34 @@ int finalize_decoder(pio_context* c) {
   if ((rc = need(c, "decoder.transformer.ln_f.bias", {E}, &tlb))) return rc;
   if ((rc = upload_ln_folded(c, tw->data.data(), false, E, V, tl->data.data(), tlb->data.data(), nullptr, &c->head_w,
                              &c->head_c, &c->head_d))) return rc;
+  {
+    // fp16 copy of the LN-folded head for the arg-max filter (decoder.hip, "LM head with an fp16 filter"): scaled by a
+    // power of two so that the largest weight sits near 2^14; the bound coefficient uses the largest row norm.
+    const float* wt = tw->data.data();
+    const float* lw = tl->data.data();
+    double amax = 0.0, nmax = 0.0;
+    for (int64_t j = 0; j < V; ++j) {
+      double nn = 0.0;
+      for (int64_t k = 0; k < E; ++k) {
+        const double f = (double)(wt[(size_t)j * E + k] * lw[k]);
+        nn += f * f;
+        amax = std::max(amax, std::fabs(f));
+      }
+      nmax = std::max(nmax, nn);
+    }
+    int sh = 0;
+    if (amax > 0.0) sh = 13 - std::ilogb(amax);                 // |W'| * 2^sh < 2^14
+    const float up = std::ldexp(1.0f, sh);
+    std::vector<uint16_t> w16((size_t)V * E);
+    for (int64_t j = 0; j < V; ++j)
+      for (int64_t k = 0; k < E; ++k) w16[(size_t)j * E + k] = f32_to_f16_bits((wt[(size_t)j * E + k] * lw[k]) * up);
+    void* d16 = nullptr;
+    if ((rc = c->dmalloc_bytes(&d16, w16.size() * 2))) return rc;
+    HIP_OK(hipMemcpy(d16, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+    c->head_w16 = (uint16_t*)d16;
+    c->head_w16_unscale = std::ldexp(1.0f, -sh);
+    c->head_bound_coef = (float)(1.25e-3 * std::sqrt(nmax) * (1.0 + 1e-6));
+  }
   c->dl.resize(L);
   for (int l = 0; l < L; ++l) {
     DecLayerW& w = c->dl[l];
@@ -351,7 +382,10 @@ int finalize_decoder(pio_context* c) {
   if ((rc = c->dmalloc(&c->splitk_cnt, 64, true))) return rc;
   if ((rc = c->dmalloc(&c->kcache, (size_t)L * N * S * E, true))) return rc;
   if ((rc = c->dmalloc(&c->vcache, (size_t)L * N * S * E, true))) return rc;
-  if ((rc = c->dmalloc(&c->logits, N * V, true))) return rc;
+  if ((rc = c->dmalloc(&c->logits, N * (size_t)round_up(V, 64), true))) return rc;
+  if ((rc = c->dmalloc_bytes(&c->dec_xh, N * E * 2, true))) return rc;
+  if ((rc = c->dmalloc(&c->lm_stats, N * 4, true))) return rc;
+  if ((rc = c->dmalloc(&c->lm_gmax, N * (size_t)round_up((V + 15) / 16, 64), true))) return rc;
   if ((rc = c->dmalloc(&c->prefix_buf, N * PS, true))) return rc;
   if ((rc = c->dmalloc(&c->logprob_buf, N * S, true))) return rc;
   if ((rc = c->dmalloc(&c->ids_buf, N * S, true))) return rc;
@@ -811,13 +845,17 @@ int pio_decode_greedy(pio_handle c, const float* prefix, int32_t N, int32_t step
   a.wte = c->wte; a.wpe = c->wpe; a.head_w = c->head_w; a.head_c = c->head_c; a.head_d = c->head_d; a.layer = c->dl.data();
   a.x = c->dx; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.splitk_ws = c->splitk_ws; a.splitk_cnt = c->splitk_cnt; a.kcache = c->kcache; a.vcache = c->vcache;
   a.max_steps = c->cfg.max_steps; a.logits = c->logits; a.ids = c->ids_buf; a.logprob = logprob ? c->logprob_buf : nullptr;
+  a.head_w16 = c->head_w16; a.head_w16_unscale = c->head_w16_unscale; a.head_bound_coef = c->head_bound_coef;
+  a.xh = c->dec_xh; a.lm_stats = c->lm_stats; a.lm_gmax = c->lm_gmax;
   HIP_OK(hipMemcpyAsync(c->prefix_buf, prefix, (size_t)N * PS * 4, hipMemcpyDeviceToDevice, s));
   HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, 64 * sizeof(unsigned), s));   // tickets start at zero whatever happened before
   // algorithmic work of a KV-cached decode: per token 4 layers x 12 E^2 MACs + the tied LM head;
   // bytes = every fp32 weight read once per step
   const double layer_params = (double)c->cfg.dec_layers * 12.0 * E * E, head_params = (double)c->cfg.dec_vocab * E;
   const double dec_flops = 2.0 * N * steps * (layer_params + head_params);
-  const double dec_bytes = 4.0 * steps * (layer_params + head_params);
+  // bytes the path streams per step: the layers in fp32; the head in fp16 when ids only are wanted (fp16 filter,
+  // plus a handful of fp32 rows for the exact re-evaluation), in fp32 when log-probabilities are
+  const double dec_bytes = steps * (4.0 * layer_params + (logprob ? 4.0 : 2.0) * head_params);
   if (c->use_graph) {
     const GraphKey key{N, steps, logprob ? 1 : 0};
     auto it = c->graphs.find(key);

@@ -128,7 +128,15 @@ struct DecoderArgs {
   int max_steps;
   float* splitk_ws;       // [64 column groups][4 k-slices][4 row groups][256] partial tiles
   unsigned* splitk_cnt;   // [64] arrival tickets (zero between launches)
-  float* logits; // [ceil(V/16)][N][4] per-workgroup (max, arg-max, sum-exp) partials of the LM head
+  float* logits; // [ceil(V/16)][N][4] per-workgroup (max, arg-max, sum-exp) partials of the LM head, or the
+                 // approximate logits [N][round_up(V, 64)] of the fp16 filter
+  // fp16 filter of the LM head (null head_w16: exact head only)
+  const uint16_t* head_w16 = nullptr;   // [V][E] fp16 bits of head_w * 2^s
+  float head_w16_unscale = 1.f;         // 2^-s
+  float head_bound_coef = 0.f;          // 1.25e-3 * max_v |head_w[v]|_2
+  void* xh = nullptr;                   // [N][E] fp16 copy of x (scaled per row)
+  float* lm_stats = nullptr;            // [N][4] mu, rstd, 2^e, error bound
+  float* lm_gmax = nullptr;             // [N][round_up(ceil(V/16), 64)] maxima of the approximate logits per 16 columns
   int32_t* ids;      // [N][steps]
   float* logprob;    // [N][steps] or null
 };

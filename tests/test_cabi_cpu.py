@@ -90,7 +90,7 @@ def test_preprocess_and_bbox_adjust():
 
 
 def test_inline_asm_weight_loads_are_not_touched_before_their_wait(tmp_path):
-    """k_lmhead_wide hides its weight loads from hipcc in inline asm (decoder.hip); hipcc then knows nothing of
+    """k_lmhead_wide / k_lmhead_f16 hide their weight loads from hipcc in inline asm (decoder.hip); hipcc then knows nothing of
     their latency, so a compiler copy of a destination register between the load and the s_waitcnt that retires it
     would read garbage.  Audit the generated ISA of every instantiation (tools/microbench/asm_load_audit.py)."""
     import re
@@ -101,8 +101,8 @@ def test_inline_asm_weight_loads_are_not_touched_before_their_wait(tmp_path):
                     "-I", os.path.join(ROOT, "patch-ioner_amd", "csrc"), "-S", "--cuda-device-only",
                     os.path.join(ROOT, "patch-ioner_amd", "csrc", "decoder.hip"), "-o", str(asm)], check=True)
     text = asm.read_text()
-    names = sorted(set(re.findall(r"^(_ZN3pio13k_lmhead_wide\w+):", text, flags=re.M)))
-    assert len(names) == 3, names
+    names = sorted(set(re.findall(r"^(_ZN3pio1[23]k_lmhead_(?:wide|f16)\w+):", text, flags=re.M)))
+    assert len(names) == 6, names
     for name in names:
         body = text[text.index(name + ":"):]
         body = body[:body.index("s_endpgm")]

@@ -319,6 +319,35 @@ def test_decoder_nan_prefix_decodes_like_torch_argmax(golden, eng224):
             assert np.array_equal(ids[r, [0, 2, 4]], g["unit_ids"][[0, 2, 4]])
 
 
+def test_lm_head_fp16_filter_equals_the_exact_head_on_adversarial_vocabularies():
+    """Greedy ids come from an fp16 filter + exact re-evaluation of every column within a proven error bound
+    (decoder.hip).  Vocabulary built to defeat a filter without the re-evaluation: every odd row of wte is its even
+    neighbour times (1 + d), d = 0 (exact ties -> the lower index must win), +-1e-4 (below fp16 resolution, far above
+    fp32 rounding).  The exact head (the log-probability path) is the reference; also with prefixes scaled by 1e3 and
+    1e-3 (per-row fp16 scaling)."""
+    from patchioner_amd.engine import Engine
+    sd = W.synth_decap(21)
+    wte = sd["decoder.transformer.wte.weight"]
+    g = torch.Generator().manual_seed(5)
+    d = torch.tensor([0.0, 1e-4, -1e-4])[torch.randint(0, 3, (24704,), generator=g)]
+    wte[1:49408:2] = wte[0:49408:2] * (1.0 + d[:, None])
+    e = Engine(embed_dim=768, depth=1, num_heads=12, num_registers=4, crop_dim=224, max_batch=2, vit_dtype="fp16")
+    try:
+        e.load_state_dict(sd)
+        e.finalize()
+        x = torch.randn(64, 768, generator=g)
+        twins = 0
+        for scale in (1.0, 1e3, 1e-3):
+            for N in (64, 16, 5):
+                ids_f, _ = e.decode_greedy((x[:N] * scale).contiguous())
+                ids_e, lp = e.decode_greedy((x[:N] * scale).contiguous(), want_logprob=True)
+                assert torch.equal(ids_f.cpu(), ids_e.cpu()), (scale, N)
+                twins += int((ids_e.cpu() % 2 == 0).sum())
+        assert twins > 0
+    finally:
+        e.close()
+
+
 # ------------------------------------------------------------------------------------------- a14/a15
 def _make_model(with_bank, **over):
     from patchioner_amd import Patchioner
