@@ -44,6 +44,9 @@ namespace pio {
 #ifndef PIO_DEC_WAVES_RG4    // waves per k_dec_gemm workgroup at 33..64 prefixes
 #define PIO_DEC_WAVES_RG4 8
 #endif
+#ifndef PIO_LMF16_NT          // which row-group counts of k_lmhead_f16 stream their weights non-temporally
+#define PIO_LMF16_NT(RG) ((RG) == 4)
+#endif
 #ifndef PIO_LMHEAD_FILTER     // greedy ids through the fp16 filter + exact re-evaluation (log-probabilities: exact head)
 #define PIO_LMHEAD_FILTER 1
 #endif
@@ -705,7 +708,8 @@ __global__ __launch_bounds__(256, 2) void k_lmhead_f16(const uint16_t* __restric
   do {                                                                                                         \
     _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                            \
       const uint16_t* _p = wp + (q) * CH + 32 * c;                                                             \
-      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(w[set][c]) : "v"(_p) : "memory");               \
+      if constexpr (PIO_LMF16_NT(RG)) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(w[set][c]) : "v"(_p) : "memory"); \
+      else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[set][c]) : "v"(_p) : "memory");            \
     }                                                                                                          \
   } while (0)
 #define PIO_WWAIT(set, cnt) asm volatile("s_waitcnt vmcnt(" #cnt ")" : "+v"(w[set][0]), "+v"(w[set][1]) :: "memory")
