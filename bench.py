@@ -122,7 +122,8 @@ def main():
     if args.mode == "group" and P > 1:
         from patchioner_amd.pipeline import TraceCaptionPipeline
         pipe = TraceCaptionPipeline(model, group_batches=P, stage_replicas=models[1:S],
-                                    stage_cus=int(os.environ.get("PIO_STAGE_CUS", "0")) or None)
+                                    stage_cus=int(os.environ.get("PIO_STAGE_CUS", "0")) or None,
+                                    decode_cus=int(os.environ.get("PIO_DECODE_CUS", "0")) or None)
 
     def run_steps(n):
         """n forwards.  mode=group: stage 1 (ViT .. projection) per batch, ONE decode per P batches, the two stages

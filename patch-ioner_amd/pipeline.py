@@ -39,7 +39,7 @@ class TraceCaptionPipeline:
     ``traces=None`` captions the CLS token instead (caption_from=cls)."""
 
     def __init__(self, model, group_batches: int = 4, use_attention_tracing: bool = False, steps: int = 30,
-                 stage_replicas: Sequence = (), stage_cus: Optional[int] = None):
+                 stage_replicas: Sequence = (), stage_cus: Optional[int] = None, decode_cus: Optional[int] = None):
         """``stage_replicas``: further Patchioner instances holding the SAME weights (each has its own ViT
         workspace); stage 1 of consecutive batches then alternates over the replicas, each on its own stream,
         so that one batch's GEMM tails, epilogues and launch gaps are filled by the other's kernels."""
@@ -52,25 +52,37 @@ class TraceCaptionPipeline:
         # kernels find idle CUs instead of queueing behind resident GEMM workgroups (None / 0: no restriction).
         self._raw_streams = []
         self.stage_streams = [self._make_stream(stage_cus) for _ in self.stage_models]
-        self.sb = self._make_stream(0)
+        # ... and the decode to the LAST `decode_cus` compute units (a true partition when stage_cus + decode_cus <= total)
+        self.sb = self._make_stream(decode_cus, from_top=True)
         self._nstaged = 0
         cap = self.eng.max_prefixes
         self.groups = [_Group(cap, self.eng.prefix_size, steps, self.eng.device) for _ in range(2)]
         self.last_ids: Optional[torch.Tensor] = None
 
-    def _make_stream(self, n_cus):
+    def _make_stream(self, n_cus, from_top: bool = False):
         if not n_cus:
             return torch.cuda.Stream()
         from ._lib import load, check
         import ctypes
         raw = ctypes.c_void_p()
-        check(load().pio_stream_create(self.eng.device.index or 0, 0, int(n_cus), ctypes.byref(raw)))
+        total = torch.cuda.get_device_properties(self.eng.device).multi_processor_count
+        skip = max(0, total - int(n_cus)) if from_top else 0
+        check(load().pio_stream_create(self.eng.device.index or 0, skip, int(n_cus), ctypes.byref(raw)))
         self._raw_streams.append(raw)
         return torch.cuda.ExternalStream(raw.value, device=self.eng.device)
 
     def close(self):
+        """Release the CU-masked streams (if any).  Everything recorded on them is dropped first: torch's
+        ExternalStream wrappers and the events of the group buffers must not outlive the raw streams."""
         from ._lib import load
         torch.cuda.synchronize()
+        for g in self.groups:
+            g.staged = []
+            g.decoded = torch.cuda.Event()
+        self.stage_streams = [torch.cuda.Stream() for _ in self.stage_models]
+        self.sb = torch.cuda.Stream()
+        import gc
+        gc.collect()
         for raw in self._raw_streams:
             load().pio_stream_destroy(raw)
         self._raw_streams = []

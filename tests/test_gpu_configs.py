@@ -159,6 +159,11 @@ def test_grouped_decode_pipeline_matches_synchronous_forward():
     want = [m(imgs, get_cls_capt=True)["cls_capt"] for imgs, _ in batches]
     got = list(TraceCaptionPipeline(m, group_batches=4).run((imgs, None) for imgs, _ in batches))
     assert got == want
+    # CU-masked streams (pio_stream_create): same captions; close() releases them and the pipeline stays usable
+    pipe = TraceCaptionPipeline(m, group_batches=4, stage_cus=192, decode_cus=64)
+    assert list(pipe.run((imgs, None) for imgs, _ in batches)) == want
+    pipe.close()
+    assert list(pipe.run((imgs, None) for imgs, _ in batches[:2])) == want[:2]
 
 
 def test_double_dino_boxes_vs_reference_golden(golden):
