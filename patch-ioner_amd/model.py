@@ -361,19 +361,16 @@ class Patchioner(nn.Module):
             else:
                 bbox_feats = self._bbox_feats(tokens, bboxes, gaussian_avg, gaussian_bbox_variance, False,
                                               self_attn if use_attn_map_for_bboxes else None).view(-1, embed_dim)
-            n_batch = math.ceil(bbox_feats.shape[0] / bbox_bs)
-            outs['bbox_capts'] = []
+            # The reference captions the boxes in chunks of bbox_bs = bs * bs_factor (model.py:1000-1033), a memory
+            # measure of its cache-less decode.  Projection and decode are row-independent, so ONE call gives the
+            # same captions / scores; the engine splits at its own capacities (16 queries per bank pass, max_prefixes
+            # per decode), e.g. 128 boxes decode as 2 x 64 instead of 4 x 32 prefixes.
+            del bbox_bs
+            ret = self.caption_tokens(bbox_feats, project=project_regions, compute_scores=compute_scores)
             if compute_scores is True:
-                outs['bbox_scores'] = []
-            for i in range(n_batch):
-                start = i * bbox_bs
-                end = start + bbox_bs if i < n_batch - 1 else bbox_feats.shape[0]
-                ret = self.caption_tokens(bbox_feats[start:end], project=project_regions, compute_scores=compute_scores)
-                if compute_scores is True:
-                    outs['bbox_capts'].extend(ret[0])
-                    outs['bbox_scores'].extend(ret[1])
-                else:
-                    outs['bbox_capts'].extend(ret)
+                outs['bbox_capts'], outs['bbox_scores'] = list(ret[0]), list(ret[1])
+            else:
+                outs['bbox_capts'] = list(ret)
             outs['bbox_capts'] = [outs['bbox_capts'][i * n_boxes:(i + 1) * n_boxes] for i in range(bs)]
             if compute_scores is True:
                 outs['bbox_scores'] = [outs['bbox_scores'][i * n_boxes:(i + 1) * n_boxes] for i in range(bs)]
