@@ -28,7 +28,7 @@ MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
-def build_models(device_index: int, count: int):
+def build_models(device_index: int, count: int, max_prefixes: int = 64):
     """`count` identical model instances (own workspaces / decode graphs / bank copy each) for `count` batches in flight."""
     from patchioner_amd import Patchioner, weights as W
     g = torch.Generator(device="cuda").manual_seed(6)
@@ -39,7 +39,7 @@ def build_models(device_index: int, count: int):
     cfg = {"decap_weights": W.synth_decap(3), "dino_weights": W.synth_dinov2(1), "memory_bank": bank,
            "prefix_size": 768, "linear_talk2dino": False, "support_memory_size": BANK_ROWS,
            "dino_model": "dinov2_vitb14_reg", "normalize": True, "resize_dim": CROP, "crop_dim": CROP,
-           "max_batch": BATCH, "max_prefixes": 64}
+           "max_batch": BATCH, "max_prefixes": max_prefixes}
     models = [Patchioner.from_config(cfg, device="cuda:%d" % device_index) for _ in range(count)]
     del bank
     torch.cuda.empty_cache()
@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("PIO_BENCH_IN_FLIGHT", "4")),
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("PIO_BENCH_IN_FLIGHT", "8")),
                     help="batches kept in flight per GPU (each on its own model instance and stream; the decode of "
                          "one batch is latency-bound and overlaps with the next batch's ViT); 1 = the reference's "
                          "synchronous forward, which is also always measured and reported as `sync`")
@@ -108,7 +108,8 @@ def main():
 
     P = max(1, args.in_flight)
     S = max(1, args.stage_streams)
-    models = build_models(local, P if args.mode == "streams" else S)
+    models = build_models(local, P if args.mode == "streams" else S,
+                          max_prefixes=min(128, max(64, BATCH * P)) if args.mode == "group" else 64)
     model = models[0]
     streams = [torch.cuda.Stream() for _ in range(P)]
     imgs, traces = make_inputs()

@@ -378,7 +378,7 @@ int finalize_decoder(pio_context* c) {
   if ((rc = c->dmalloc(&c->dqkv, N * 3 * E, true))) return rc;
   if ((rc = c->dmalloc(&c->datt, N * E, true))) return rc;
   if ((rc = c->dmalloc(&c->dhid, N * 4 * E, true))) return rc;
-  if ((rc = c->dmalloc(&c->splitk_ws, (size_t)64 * 4 * 4 * 256, true))) return rc;
+  if ((rc = c->dmalloc(&c->splitk_ws, (size_t)64 * 4 * 8 * 256, true))) return rc;   // 64 column groups x 4 k-slices x 8 row groups
   if ((rc = c->dmalloc(&c->splitk_cnt, 64, true))) return rc;
   if ((rc = c->dmalloc(&c->kcache, (size_t)L * N * S * E, true))) return rc;
   if ((rc = c->dmalloc(&c->vcache, (size_t)L * N * S * E, true))) return rc;
@@ -499,8 +499,8 @@ int pio_create(const pio_config* cfg, pio_handle* out) {
     return fail(PIO_ERR_INVALID_ARG, "pio_create: backbone head_dim must be 64 (embed_dim = 64 * num_heads)");
   if (cfg->crop_dim % cfg->patch_size != 0)
     return fail(PIO_ERR_INVALID_ARG, "pio_create: crop_dim must be a multiple of patch_size");
-  if (cfg->max_batch < 1 || cfg->max_prefixes < 1 || cfg->max_prefixes > 64 || cfg->max_steps < 1 || cfg->max_steps > 64)
-    return fail(PIO_ERR_INVALID_ARG, "pio_create: capacities out of range (prefixes <= 64, steps <= 64)");
+  if (cfg->max_batch < 1 || cfg->max_prefixes < 1 || cfg->max_prefixes > 128 || cfg->max_steps < 1 || cfg->max_steps > 64)
+    return fail(PIO_ERR_INVALID_ARG, "pio_create: capacities out of range (prefixes <= 128, steps <= 64)");
   if (cfg->readout_heads != 16 && cfg->readout_heads * 64 != cfg->embed_dim)
     return fail(PIO_ERR_INVALID_ARG, "pio_create: readout_heads must be 16, or embed_dim / 64 (ViT-S: 6)");
   int ndev = 0;
@@ -835,6 +835,7 @@ int pio_decode_greedy(pio_handle c, const float* prefix, int32_t N, int32_t step
   if (!c || !prefix || !ids) return fail(PIO_ERR_INVALID_ARG, "pio_decode_greedy: null argument");
   if (!c->has_dec) return fail(PIO_ERR_NOT_READY, "pio_decode_greedy: decoder weights not loaded");
   if (N < 1 || N > c->cfg.max_prefixes) return fail(PIO_ERR_CAPACITY, "pio_decode_greedy: N above max_prefixes");
+  if (logprob && N > 64) return fail(PIO_ERR_CAPACITY, "pio_decode_greedy: log-probabilities are built for <= 64 prefixes per call");
   if (steps < 1 || steps > c->cfg.max_steps) return fail(PIO_ERR_CAPACITY, "pio_decode_greedy: steps above max_steps");
   HIP_OK(hipSetDevice(c->cfg.device));
   hipStream_t s = (hipStream_t)stream;

@@ -45,7 +45,7 @@ namespace pio {
 #define PIO_DEC_WAVES_RG4 8
 #endif
 #ifndef PIO_LMF16_NT          // which row-group counts of k_lmhead_f16 stream their weights non-temporally
-#define PIO_LMF16_NT(RG) ((RG) == 4)
+#define PIO_LMF16_NT(RG) ((RG) >= 4)
 #endif
 #ifndef PIO_LMHEAD_FILTER     // greedy ids through the fp16 filter + exact re-evaluation (log-probabilities: exact head)
 #define PIO_LMHEAD_FILTER 1
@@ -415,6 +415,9 @@ static hipError_t dec_gemm_rg(const float* W, const float* X, int N, int Nout, i
   else if (rg <= 4) {
     if constexpr (PIO_DEC_WAVES_RG4 == 8 && CPW % 4 == 0 && EPI != DE_ARGMAX) PIO_DG(4, CPW / 2, 8);
     else PIO_DG(4, CPW, 4);
+  } else if (rg <= 8) {
+    if constexpr (EPI != DE_ARGMAX) PIO_DG(8, CPW, 4);     // 65..128 prefixes (ids-only decode): 4 waves, 32 KiB of LDS partials
+    else return hipErrorInvalidValue;
   } else return hipErrorInvalidValue;
 #undef PIO_DG
   return hipGetLastError();
@@ -424,7 +427,7 @@ static hipError_t dec_gemm_rg(const float* W, const float* X, int N, int Nout, i
 template <int EPI, int LN>
 static hipError_t dec_gemm(const float* W, const float* X, int N, int Nout, int K, const float* bias, float* out,
                            const float* extra, const float* cvec, float eps, float* ws, unsigned* cnt, hipStream_t s) {
-  if (N < 1 || N > 64) return hipErrorInvalidValue;
+  if (N < 1 || N > 128) return hipErrorInvalidValue;
   if (K == 768) return dec_gemm_rg<12, 1, EPI, LN>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);
   if (K == 512) return dec_gemm_rg<8, 1, EPI, LN>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);
   if (K == 384) return dec_gemm_rg<6, 1, EPI, LN>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);   // ViT-S prefix
@@ -864,7 +867,8 @@ static hipError_t launch_lmhead_filtered(const DecoderArgs& a, int step, hipStre
   const int rg = ceil_div(a.N, 16);
   if (rg <= 1) e = launch_lmhead_f16<1>(a, s);
   else if (rg <= 2) e = launch_lmhead_f16<2>(a, s);
-  else e = launch_lmhead_f16<4>(a, s);
+  else if (rg <= 4) e = launch_lmhead_f16<4>(a, s);
+  else e = launch_lmhead_f16<8>(a, s);
   if (e != hipSuccess) return e;
   const int NG = ceil_div(a.vocab, 16), NGp = round_up(NG, 64);
   if (NG > 4096) return hipErrorInvalidValue;
@@ -891,7 +895,10 @@ hipError_t launch_lmhead(const float* W, const float* X, int N, int V, int E, co
 
 hipError_t launch_decode_greedy(const DecoderArgs& a, hipStream_t s) {
   const int N = a.N, E = a.E;
-  if (a.steps > a.max_steps || a.steps > 64 || E != 768 || (E / a.heads) % 32 != 0 || (E / a.heads) > 256 || N > 64)
+  const bool filtered = PIO_LMHEAD_FILTER && a.logprob == nullptr && a.head_w16 != nullptr;
+  // 65..128 prefixes only through the filtered (ids-only) head; the exact head is built for <= 64
+  if (a.steps > a.max_steps || a.steps > 64 || E != 768 || (E / a.heads) % 32 != 0 || (E / a.heads) > 256 ||
+      N > (filtered ? 128 : 64))
     return hipErrorInvalidValue;
   if (ceil_div(a.vocab, 16) > 4096) return hipErrorInvalidValue;
   // step 0 input: clip_project(prefix) + wpe[0]   (decap.py:124; GPT-2 adds wpe to inputs_embeds)
@@ -908,7 +915,7 @@ hipError_t launch_decode_greedy(const DecoderArgs& a, hipStream_t s) {
       PIO_TRY((dec_gemm<DE_GELU, 1>(w.fc_w, a.x, N, 4 * E, E, w.fc_d, a.hid, nullptr, w.fc_c, a.eps, nullptr, nullptr, s)));
       PIO_TRY((dec_gemm<DE_RESID, 0>(w.fc2_w, a.hid, N, E, 4 * E, w.fc2_b, a.x, nullptr, nullptr, 0.f, a.splitk_ws, a.splitk_cnt, s)));
     }
-    if (PIO_LMHEAD_FILTER && a.logprob == nullptr && a.head_w16 != nullptr) {
+    if (filtered) {
       PIO_TRY(launch_lmhead_filtered(a, step, s));
       continue;
     }

@@ -311,8 +311,9 @@ class Engine:
         N = prefix.shape[0]
         ids = torch.empty(N, steps, device=self.device, dtype=torch.int32)
         lp = torch.empty(N, steps, device=self.device, dtype=torch.float32) if want_logprob else None
-        for s in range(0, N, self.max_prefixes):
-            e = min(N, s + self.max_prefixes)
+        chunk = min(self.max_prefixes, 64) if want_logprob else self.max_prefixes     # the exact (log-prob) head: <= 64 rows
+        for s in range(0, N, chunk):
+            e = min(N, s + chunk)
             check(self.lib.pio_decode_greedy(self.h, ptr(prefix[s:e]), e - s, steps, ptr(ids[s:e]),
                                              ptr(lp[s:e]) if want_logprob else None, _stream()))
         return ids, lp

@@ -303,6 +303,30 @@ def test_decoder_batch_sizes_and_graph_reuse(golden, eng224):
         assert np.array_equal(ids.cpu().numpy(), np.tile(want, (5, 1)))
 
 
+def test_decoder_128_prefixes_in_one_call(golden):
+    """max_prefixes = 128: 8 row groups through the ids-only (filtered) head in ONE decode; log-probabilities still come
+    from the exact head in chunks of 64.  Per-row ids equal the golden ids whatever the batch composition."""
+    from patchioner_amd.engine import Engine
+    g = golden("decoder")
+    e = Engine(embed_dim=768, depth=1, num_heads=12, num_registers=4, crop_dim=224, max_batch=2, max_prefixes=128, vit_dtype="fp16")
+    try:
+        e.load_state_dict(W.synth_dinov2(gc.E2E["seed_vit"], depth=1))
+        e.load_state_dict(W.synth_decap(gc.DEC["seed_w"]))
+        e.finalize()
+        x = gc.decoder_prefixes("unit")
+        want = g["unit_ids"]
+        reps = -(-128 // x.shape[0])
+        big = x.repeat(reps, 1)[:128]
+        ids, _ = e.decode_greedy(big)
+        assert np.array_equal(ids.cpu().numpy(), np.tile(want, (reps, 1))[:128])
+        ids97, _ = e.decode_greedy(big[:97])                      # ragged: 7 row groups, the last one partial
+        assert np.array_equal(ids97.cpu().numpy(), np.tile(want, (reps, 1))[:97])
+        ids_lp, lp = e.decode_greedy(big, want_logprob=True)       # 2 x 64 through the exact head
+        assert np.array_equal(ids_lp.cpu().numpy(), np.tile(want, (reps, 1))[:128]) and lp.shape == (128, 30)
+    finally:
+        e.close()
+
+
 def test_decoder_nan_prefix_decodes_like_torch_argmax(golden, eng224):
     """A prefix of NaNs (the reference's mean over an empty box region, bbox_utils.py:40-42 / 393) makes every logit NaN;
     torch.argmax then returns index 0.  The GPU arg-max orders NaN like torch (and never indexes wte out of range);
