@@ -8,7 +8,7 @@ from patchioner_amd.pipeline import TraceCaptionPipeline
 
 torch.set_grad_enabled(False)
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-model = bench.build_models(0, 1)[0]
+model = bench.build_models(0, 1, max_prefixes=min(128, max(64, 16 * G)))[0]
 imgs, traces = bench.make_inputs()
 pipe = TraceCaptionPipeline(model, group_batches=G)
 ev = lambda: torch.cuda.Event(enable_timing=True)
