@@ -7,7 +7,7 @@ import golden_cases as gc
 from patchioner_amd.engine import Engine
 e = Engine(embed_dim=768, depth=1, num_heads=12, num_registers=4, crop_dim=224, max_batch=2, vit_dtype="fp16")
 raw = [gc.prep_image(300 + i, 640, 480) for i in range(16)]
-for _ in range(3): e.preprocess(raw, 224, 224)
+for _ in range(9): e.preprocess(raw, 224, 224)
 torch.cuda.synchronize()
 t = time.perf_counter()
 for _ in range(20): out = e.preprocess(raw, 224, 224)
