@@ -23,6 +23,9 @@
 
 namespace pio {
 
+#ifndef PIO_PROJECT_Q32       // 32 queries per bank pass when more than 16 are left
+#define PIO_PROJECT_Q32 1
+#endif
 #ifndef PIO_PROJECT_NT
 #define PIO_PROJECT_NT 1
 #endif
@@ -68,18 +71,24 @@ __global__ __launch_bounds__(256) void k_row_inv_norm(const float* __restrict__ 
   if ((threadIdx.x & 63) == 0) inv[row] = 1.0f / sqrtf(s);
 }
 
-template <int D>
-__global__ __launch_bounds__(256, 2) void k_project(const float* __restrict__ bank, const float* __restrict__ inv_norm,
+// NQG = query groups of 16 per pass: 1 (256 threads, two workgroups per CU) or 2 (512 threads, one per CU: waves 0-3
+// take queries q0..q0+15, waves 4-7 the next 16, both on the SAME bank tile in LDS, so a pass over the bank serves 32
+// queries -- the pipeline projects two image batches per pass).
+template <int D, int NQG>
+__global__ __launch_bounds__(256 * NQG, NQG == 1 ? 2 : 1) void k_project(const float* __restrict__ bank, const float* __restrict__ inv_norm,
                                                     int64_t M, const float* __restrict__ q, int N, int q0,
                                                     float temperature, float* part_acc, float* part_ml, int parts) {
   constexpr int STRIDE = D + 4;                  // floats; +16 B skews rows across the 64 banks
   constexpr int DW = D / 4;                      // channels per wave
-  constexpr int NV = D / 4 * PR_ROWS / 256;      // float4 per thread per tile
-  static_assert(D % 64 == 0 && (D / 4 * PR_ROWS) % 256 == 0, "D");
+  constexpr int NT = 256 * NQG;                  // threads
+  constexpr int NV = D / 4 * PR_ROWS / NT;       // float4 per thread per tile
+  constexpr int NQ = PR_Q * NQG;                 // queries per pass
+  static_assert(D % 64 == 0 && (D / 4 * PR_ROWS) % NT == 0, "D");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* s_bank = lds;                            // [16][STRIDE]  (single buffer: two workgroups share a CU)
-  float* s_red = lds + PR_ROWS * STRIDE;          // [4][256]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = (tid >> 6) & 3, grp = tid >> 8;  // channel slice of the wave, query group of the wave
+  float* s_red = lds + PR_ROWS * STRIDE + grp * 4 * 256;   // [NQG][4][256]
   const int li = lane & 15, kq = lane >> 4;
 
   // slab of rows for this workgroup (multiple of 16 rows)
@@ -95,7 +104,8 @@ __global__ __launch_bounds__(256, 2) void k_project(const float* __restrict__ ba
 #pragma unroll
   for (int c = 0; c < DW / 16; ++c) {
     qreg[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q0 + li < N) qreg[c] = *(const float4*)(q + (size_t)(q0 + li) * D + wid * DW + 16 * c + 4 * kq);
+    if (q0 + 16 * grp + li < N)
+      qreg[c] = *(const float4*)(q + (size_t)(q0 + 16 * grp + li) * D + wid * DW + 16 * c + 4 * kq);
   }
 
   // Per-thread staging of the next tile: NV <= 12 float4 held in NAMED registers (hipcc keeps a staged
@@ -105,9 +115,9 @@ __global__ __launch_bounds__(256, 2) void k_project(const float* __restrict__ ba
   // non-temporal: the bank is read once per call and is 7x the Infinity Cache; a default-policy stream evicts the
   // ViT / decoder weights that the next kernels want to find there
 #define PIO_BANK_SRC(t, i) \
-  ld_stream4(bank + (((t) * PR_ROWS + (tid + 256 * (i)) / (D / 4)) < M ? ((t) * PR_ROWS + (tid + 256 * (i)) / (D / 4)) : M - 1) * D + 4 * ((tid + 256 * (i)) % (D / 4)))
+  ld_stream4(bank + (((t) * PR_ROWS + (tid + NT * (i)) / (D / 4)) < M ? ((t) * PR_ROWS + (tid + NT * (i)) / (D / 4)) : M - 1) * D + 4 * ((tid + NT * (i)) % (D / 4)))
 #define PIO_BANK_DST(buf, i) \
-  (*(float4*)(s_bank + ((tid + 256 * (i)) / (D / 4)) * STRIDE + 4 * ((tid + 256 * (i)) % (D / 4))))
+  (*(float4*)(s_bank + ((tid + NT * (i)) / (D / 4)) * STRIDE + 4 * ((tid + NT * (i)) % (D / 4))))
 #define PIO_LOAD_BANK(t)                                  \
   do {                                                    \
     if constexpr (NV > 0) g0 = PIO_BANK_SRC(t, 0);        \
@@ -223,14 +233,14 @@ __global__ __launch_bounds__(256, 2) void k_project(const float* __restrict__ ba
 #undef PIO_BANK_DST
 
   // ---- partial results: part_acc[block][n][D], part_ml[block][n][2] ----
-  float* pa = part_acc + (size_t)blockIdx.x * PR_Q * D;
+  float* pa = part_acc + ((size_t)blockIdx.x * NQ + 16 * grp) * D;
 #pragma unroll
   for (int j = 0; j < DW / 16; ++j)
 #pragma unroll
     for (int i = 0; i < 4; ++i) pa[(size_t)(4 * kq + i) * D + wid * DW + 16 * j + li] = acc[j][i];
   if (wid == 0 && kq == 0) {
-    part_ml[((size_t)blockIdx.x * PR_Q + li) * 2 + 0] = m_run;
-    part_ml[((size_t)blockIdx.x * PR_Q + li) * 2 + 1] = l_run;
+    part_ml[((size_t)blockIdx.x * NQ + 16 * grp + li) * 2 + 0] = m_run;
+    part_ml[((size_t)blockIdx.x * NQ + 16 * grp + li) * 2 + 1] = l_run;
   }
 }
 
@@ -238,13 +248,13 @@ __global__ __launch_bounds__(256, 2) void k_project(const float* __restrict__ ba
 // One workgroup per (query, 64 channels): lane = channel, the 4 waves split the partials.
 __global__ __launch_bounds__(256) void k_project_combine(const float* __restrict__ part_acc,
                                                          const float* __restrict__ part_ml, int parts, int D, int q0,
-                                                         float* out) {
+                                                         int qstride, float* out) {
   __shared__ float s_w[1024];
   __shared__ float red[4];
   __shared__ float s_acc[4][64];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   float mx = -INFINITY;
-  for (int b = tid; b < parts; b += 256) mx = fmaxf(mx, part_ml[((size_t)b * PR_Q + n) * 2]);
+  for (int b = tid; b < parts; b += 256) mx = fmaxf(mx, part_ml[((size_t)b * qstride + n) * 2]);
   mx = wave_max(mx);
   if (lane == 0) red[wid] = mx;
   __syncthreads();
@@ -252,10 +262,10 @@ __global__ __launch_bounds__(256) void k_project_combine(const float* __restrict
   __syncthreads();
   float ls = 0.f;
   for (int b = tid; b < parts; b += 256) {
-    const float mb = part_ml[((size_t)b * PR_Q + n) * 2];
+    const float mb = part_ml[((size_t)b * qstride + n) * 2];
     const float w = (mb == -INFINITY) ? 0.f : expf(mb - mx);   // workgroups with an empty slab
     s_w[b] = w;
-    ls += w * part_ml[((size_t)b * PR_Q + n) * 2 + 1];
+    ls += w * part_ml[((size_t)b * qstride + n) * 2 + 1];
   }
   ls = wave_sum(ls);
   if (lane == 0) red[wid] = ls;
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(256) void k_project_combine(const float* __restrict
   const int d = blockIdx.y * 64 + lane;
   float a = 0.f;
 #pragma unroll 8
-  for (int b = wid; b < parts; b += 4) a += s_w[b] * part_acc[((size_t)b * PR_Q + n) * D + d];
+  for (int b = wid; b < parts; b += 4) a += s_w[b] * part_acc[((size_t)b * qstride + n) * D + d];
   s_acc[wid][lane] = a;
   __syncthreads();
   if (wid == 0) out[(size_t)(q0 + n) * D + d] = ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane])) * inv_l;
@@ -332,35 +342,45 @@ __global__ __launch_bounds__(256) void k_revert(const float* __restrict__ x, con
   if (lane == 0) out[(size_t)n * P + p] = s;
 }
 
-template <int D>
-static hipError_t project_pass(const ProjectArgs& a, int q0, hipStream_t s) {
-  const int smem = (PR_ROWS * (D + 4) + 4 * 256) * (int)sizeof(float);
+template <int D, int NQG>
+static hipError_t project_pass(const ProjectArgs& a, int q0, int parts, hipStream_t s) {
+  const int smem = (PR_ROWS * (D + 4) + NQG * 4 * 256) * (int)sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_project<D>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)k_project<D, NQG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_project<D>), dim3(a.parts), dim3(256), smem, s, a.bank, a.inv_norm, a.M, a.q, a.N, q0,
-                     a.temperature, a.part_acc, a.part_ml, a.parts);
+  hipLaunchKernelGGL((k_project<D, NQG>), dim3(parts), dim3(256 * NQG), smem, s, a.bank, a.inv_norm, a.M, a.q, a.N, q0,
+                     a.temperature, a.part_acc, a.part_ml, parts);
   return hipGetLastError();
 }
 
+template <int NQG>
+static hipError_t project_pass_d(const ProjectArgs& a, int q0, int parts, hipStream_t s) {
+  switch (a.D) {
+    case 384: return project_pass<384, NQG>(a, q0, parts, s);
+    case 512: return project_pass<512, NQG>(a, q0, parts, s);
+    case 768: return project_pass<768, NQG>(a, q0, parts, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_mem_project(const ProjectArgs& a, hipStream_t s) {
-  if (a.N <= 0 || a.M <= 0 || a.parts > 1024) return hipErrorInvalidValue;
+  if (a.N <= 0 || a.M <= 0 || a.parts > 1024 || a.parts < 2) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_l2norm_rows, dim3(a.N), dim3(256), 0, s, a.q, a.D);
-  for (int q0 = 0; q0 < a.N; q0 += PR_Q) {
-    hipError_t e;
-    switch (a.D) {
-      case 384: e = project_pass<384>(a, q0, s); break;
-      case 512: e = project_pass<512>(a, q0, s); break;
-      case 768: e = project_pass<768>(a, q0, s); break;
-      default: return hipErrorInvalidValue;
-    }
+  for (int q0 = 0; q0 < a.N;) {
+    // more than 16 queries left: one pass of 32 (512-thread workgroups, one per CU: parts / 2 of them, same partial
+    // buffers with 32 queries per workgroup); else a pass of 16
+    const int left = a.N - q0;
+    const bool wide = PIO_PROJECT_Q32 && left > PR_Q;
+    const int nq = wide ? (left < 2 * PR_Q ? left : 2 * PR_Q) : (left < PR_Q ? left : PR_Q);
+    const int parts = wide ? a.parts / 2 : a.parts;
+    const hipError_t e = wide ? project_pass_d<2>(a, q0, parts, s) : project_pass_d<1>(a, q0, parts, s);
     if (e != hipSuccess) return e;
-    const int nq = (a.N - q0) < PR_Q ? (a.N - q0) : PR_Q;
-    hipLaunchKernelGGL(k_project_combine, dim3(nq, a.D / 64), dim3(256), 0, s, a.part_acc, a.part_ml, a.parts, a.D,
-                       q0, a.out);
+    hipLaunchKernelGGL(k_project_combine, dim3(nq, a.D / 64), dim3(256), 0, s, a.part_acc, a.part_ml, parts, a.D,
+                       q0, wide ? 2 * PR_Q : PR_Q, a.out);
+    q0 += nq;
   }
   if (a.normalize) hipLaunchKernelGGL(k_l2norm_rows, dim3(a.N), dim3(256), 0, s, a.out, a.D);
   if (a.n_best > 0) {
