@@ -47,6 +47,9 @@ namespace pio {
 #ifndef PIO_LMF16_NT          // which row-group counts of k_lmhead_f16 stream their weights non-temporally
 #define PIO_LMF16_NT(RG) ((RG) >= 4)
 #endif
+#ifndef PIO_LMF16_FUSED       // <= 16 prefixes: statistics / fp16 conversion inside the head kernel
+#define PIO_LMF16_FUSED 1
+#endif
 #ifndef PIO_LMHEAD_FILTER     // greedy ids through the fp16 filter + exact re-evaluation (log-probabilities: exact head)
 #define PIO_LMHEAD_FILTER 1
 #endif
@@ -766,6 +769,115 @@ __global__ __launch_bounds__(256, 2) void k_lmhead_f16(const uint16_t* __restric
     }
 }
 
+// <= 16 prefixes: k_lm_prep folded into the head (one kernel less per step).  Every workgroup recomputes the rows'
+// LayerNorm statistics and fp16 copies (49 KB of x from L2) and keeps ALL of X~ (16 x 768 fp16 = 24 KB, the same
+// chunked, swizzled image as above) in LDS: nothing to stage per chunk, no barrier in the K loop.  Workgroup 0
+// publishes the statistics for k_dec_select_filter.
+__global__ __launch_bounds__(256, 2) void k_lmhead_f16_fused(const uint16_t* __restrict__ W16, const float* __restrict__ x, int N, int V,
+                                                             int Vp, float eps, float bound_coef, float* __restrict__ stats,
+                                                             const float* __restrict__ dvec, const float* __restrict__ cvec,
+                                                             float w_unscale, float* __restrict__ out, float* __restrict__ gmax, int NGp) {
+  constexpr int K = 768, CH = 64, NCH = K / CH;
+  __shared__ __attribute__((aligned(16))) char xs[NCH * 16 * 128];      // [chunk][row][64 fp16], 16-B slots XORed with (row>>1)&7
+  __shared__ __attribute__((aligned(16))) float s_st[16][4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int blk = blockIdx.x * 4 + wid;
+  const int j = blk * 16 + li;
+  const int jc = j < V ? j : V - 1;
+  const uint16_t* wp = W16 + (size_t)jc * K + 8 * kq;
+#define PIO_WLOAD(set, q)                                                                                      \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                            \
+      const uint16_t* _p = wp + (q) * CH + 32 * c;                                                             \
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[set][c]) : "v"(_p) : "memory");                  \
+    }                                                                                                          \
+  } while (0)
+#define PIO_WWAIT(set, cnt) asm volatile("s_waitcnt vmcnt(" #cnt ")" : "+v"(w[set][0]), "+v"(w[set][1]) :: "memory")
+  f32x4 w[3][2];
+  // ---- rows 4 wid .. 4 wid + 3: statistics, scale, fp16 image ----
+  float4 xv[4][3];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * wid + r, rc = row < N ? row : N - 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xv[r][i] = *(const float4*)(x + (size_t)rc * K + 4 * lane + 256 * i);
+  }
+  PIO_WLOAD(0, 0);
+  PIO_WLOAD(1, 1);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * wid + r;
+    float sum = 0.f, sq = 0.f, amax = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float4 v = xv[r][i];
+      sum += (v.x + v.y) + (v.z + v.w);
+      sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      bad |= !(fabsf(v.x) < 3.0e38f) || !(fabsf(v.y) < 3.0e38f) || !(fabsf(v.z) < 3.0e38f) || !(fabsf(v.w) < 3.0e38f);
+    }
+    sum = wave_sum(sum); sq = wave_sum(sq); amax = wave_max(amax);
+    const bool finite = !__any(bad);
+    const float mu = sum / (float)K;
+    const float var = fmaxf(sq / (float)K - mu * mu, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    int e = 0;
+    if (finite && amax > 0.f) e = ilogbf(amax) + 1 - 14;
+    const float down = ldexpf(1.0f, -e);
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int k = 4 * lane + 256 * i;                         // 4 consecutive k inside one 16-B slot
+      const float4 v = xv[r][i];
+      h4 hv;
+      hv[0] = (_Float16)(finite ? v.x * down : 0.f); hv[1] = (_Float16)(finite ? v.y * down : 0.f);
+      hv[2] = (_Float16)(finite ? v.z * down : 0.f); hv[3] = (_Float16)(finite ? v.w * down : 0.f);
+      const int q = k >> 6, slot = (k & 63) >> 3;
+      *(h4*)(xs + q * 2048 + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4) + (k & 7) * 2) = hv;
+    }
+    if (lane == 0) {
+      const float bnd = finite ? bound_coef * rstd * sqrtf(sq) : NAN;
+      s_st[row][0] = mu; s_st[row][1] = rstd; s_st[row][2] = ldexpf(1.0f, e); s_st[row][3] = bnd;
+      if (blockIdx.x == 0 && row < N) {
+        float* st = stats + 4 * row;
+        st[0] = mu; st[1] = rstd; st[2] = ldexpf(1.0f, e); st[3] = bnd;
+      }
+    }
+  }
+  __syncthreads();
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int r = q % 3;
+    if (q + 1 < NCH) PIO_WWAIT(r, 2);            // queue: W(q) | W(q+1)
+    else PIO_WWAIT(r, 0);
+    if (q + 2 < NCH) PIO_WLOAD((r + 2) % 3, q + 2);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const dec_h8 xf = *(const dec_h8*)(xs + q * 2048 + li * 128 + (((4 * c + kq) ^ ((li >> 1) & 7)) << 4));
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, __builtin_bit_cast(dec_h8, w[r][c]), acc, 0, 0, 0);
+    }
+  }
+#undef PIO_WLOAD
+#undef PIO_WWAIT
+  if (blk * 16 >= V) return;
+  const float cj = cvec[jc], dj = dvec[jc];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = 4 * kq + i;
+    const float4 st = *(const float4*)s_st[n];
+    const float v = j < V ? st.y * (acc[i] * (st.z * w_unscale) - st.x * cj) + dj : -INFINITY;
+    if (n < N && j < V) out[(size_t)n * Vp + j] = v;
+    float gm = v;
+    gm = fmaxf(gm, __shfl_xor(gm, 1)); gm = fmaxf(gm, __shfl_xor(gm, 2));
+    gm = fmaxf(gm, __shfl_xor(gm, 4)); gm = fmaxf(gm, __shfl_xor(gm, 8));
+    if (li == 0 && n < N) gmax[(size_t)n * NGp + blk] = gm;
+  }
+}
+
 // Per row: max of the approximate logits (from the per-16-column group maxima), exact re-evaluation of every column
 // within the bound, next-step input.  Groups whose maximum passes the threshold go to a list in LDS (a handful per
 // row); should more than CAND groups pass, every group is walked instead (same result, slower).
@@ -862,10 +974,18 @@ static hipError_t launch_lmhead_f16(const DecoderArgs& a, hipStream_t s) {
 
 static hipError_t launch_lmhead_filtered(const DecoderArgs& a, int step, hipStream_t s) {
   const int Vp = round_up(a.vocab, 64);
-  hipLaunchKernelGGL(k_lm_prep, dim3(a.N), dim3(256), 0, s, a.x, a.E, a.eps, a.head_bound_coef, (_Float16*)a.xh, a.lm_stats);
   hipError_t e;
   const int rg = ceil_div(a.N, 16);
-  if (rg <= 1) e = launch_lmhead_f16<1>(a, s);
+  if (PIO_LMF16_FUSED && rg <= 1) {
+    const int NGp1 = round_up(ceil_div(a.vocab, 16), 64);
+    hipLaunchKernelGGL(k_lmhead_f16_fused, dim3(ceil_div(a.vocab, 64)), dim3(256), 0, s, a.head_w16, a.x, a.N, a.vocab, Vp, a.eps,
+                       a.head_bound_coef, a.lm_stats, a.head_d, a.head_c, a.head_w16_unscale, a.logits, a.lm_gmax, NGp1);
+    e = hipGetLastError();
+  } else {
+    hipLaunchKernelGGL(k_lm_prep, dim3(a.N), dim3(256), 0, s, a.x, a.E, a.eps, a.head_bound_coef, (_Float16*)a.xh, a.lm_stats);
+  }
+  if (PIO_LMF16_FUSED && rg <= 1) {}
+  else if (rg <= 1) e = launch_lmhead_f16<1>(a, s);
   else if (rg <= 2) e = launch_lmhead_f16<2>(a, s);
   else if (rg <= 4) e = launch_lmhead_f16<4>(a, s);
   else e = launch_lmhead_f16<8>(a, s);

@@ -101,8 +101,8 @@ def test_inline_asm_weight_loads_are_not_touched_before_their_wait(tmp_path):
                     "-I", os.path.join(ROOT, "patch-ioner_amd", "csrc"), "-S", "--cuda-device-only",
                     os.path.join(ROOT, "patch-ioner_amd", "csrc", "decoder.hip"), "-o", str(asm)], check=True)
     text = asm.read_text()
-    names = sorted(set(re.findall(r"^(_ZN3pio1[23]k_lmhead_(?:wide|f16)\w+):", text, flags=re.M)))
-    assert len(names) == 7, names        # k_lmhead_wide<1,2,4>, k_lmhead_f16<1,2,4,8>
+    names = sorted(set(re.findall(r"^(_ZN3pio\d+k_lmhead_(?:wide|f16)\w+):", text, flags=re.M)))
+    assert len(names) == 8, names        # k_lmhead_wide<1,2,4>, k_lmhead_f16<1,2,4,8>, k_lmhead_f16_fused
     for name in names:
         body = text[text.index(name + ":"):]
         body = body[:body.index("s_endpgm")]
