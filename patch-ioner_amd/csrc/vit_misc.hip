@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256) void k_box_sequences(const float* __restrict__
   const int s = blockIdx.y, t = blockIdx.x;      // s: sequence inside this chunk; s_base + s: (image, box) index
   const int b = (s_base + s) / NB;
   const int32_t* sl = slices + 4 * (size_t)(s_base + s);
-  const int ys = sl[0], ye = sl[1], xs = sl[2], xe = sl[3];
+  // slices are python-normalised by the caller; clamped here so that a bad table can never index outside the grid
+  const int ys = min(max(sl[0], 0), n), ye = min(max(sl[1], 0), n), xs = min(max(sl[2], 0), n), xe = min(max(sl[3], 0), n);
   const int hh = ye > ys ? ye - ys : 0, ww = xe > xs ? xe - xs : 0;
   const int Gs = use_global ? G : 0;
   const int len = Gs + hh * ww;
