@@ -465,3 +465,35 @@ def test_forward_async_matches_forward_and_overlaps_instances():
         assert got == want and set(got) == {"cls_capt", "avg_self_attn_capt", "trace_capts"}
     with pytest.raises(NotImplementedError):
         m1.forward_async(imgs, bboxes=gc.e2e_boxes())
+
+
+def test_c_abi_rejects_out_of_contract_calls(eng224):
+    """Error behaviour of the C ABI: capacity and argument violations come back as a negative status with a message
+    (PioError), never as a silent wrong answer or a fault."""
+    e = eng224
+    import ctypes
+    from patchioner_amd._lib import load, ptr
+    lib = load()
+    tokens9, _ = e.vit_forward(torch.zeros(9, 3, 224, 224), want_qkv=False)   # above max_batch = 8: chunked by the engine
+    assert tokens9.shape == (9, 261, 768)
+    imgs9 = torch.zeros(9, 3, 224, 224, device="cuda")
+    assert lib.pio_vit_forward(e.h, ptr(imgs9), 9, ptr(tokens9), None, None) < 0 and b"max_batch" in lib.pio_last_error()
+    with pytest.raises(ValueError):
+        e.vit_forward(torch.zeros(2, 3, 210, 210))                       # not crop_dim: the reference's reshape fails too
+    x = torch.randn(65, 768)
+    ids, _ = e.decode_greedy(x)                                          # above max_prefixes = 64: chunked by the engine
+    assert ids.shape == (65, 30)
+    xd = x.cuda()
+    out = torch.empty(65, 30, dtype=torch.int32, device="cuda")
+    assert lib.pio_decode_greedy(e.h, ptr(xd), 65, 30, ptr(out), None, None) < 0 and b"max_prefixes" in lib.pio_last_error()
+    assert lib.pio_decode_greedy(e.h, ptr(xd), 4, 31, ptr(out), None, None) < 0 and b"max_steps" in lib.pio_last_error()
+    assert lib.pio_decode_greedy(e.h, None, 4, 30, ptr(out), None, None) < 0
+    tok = torch.zeros(1, 261, 768, device="cuda")
+    sl = torch.zeros(1, 4, dtype=torch.int32, device="cuda")
+    o = torch.empty(1, 768, device="cuda")
+    assert lib.pio_bbox_double_dino(e.h, ptr(tok), ptr(sl), 1, 1, 0, 0, ptr(o), None) < 0      # "cls" without cls
+    assert lib.pio_ctx_clean(e.h, ptr(tok), ptr(o), 261, 768, 261, 2, ctypes.c_float(1.0), 0, ptr(tok), None) < 0
+    off = (ctypes.c_int64 * 1)(0)
+    wh = (ctypes.c_int32 * 2)(0, 5)
+    assert lib.pio_preprocess(e.h, ptr(tok), off, wh, 1, 224, 224, 0, ptr(tok), None) < 0 and b"empty image" in lib.pio_last_error()
+    torch.cuda.synchronize()
