@@ -90,9 +90,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("PIO_BENCH_IN_FLIGHT", "8")),
-                    help="batches kept in flight per GPU (each on its own model instance and stream; the decode of "
-                         "one batch is latency-bound and overlaps with the next batch's ViT); 1 = the reference's "
-                         "synchronous forward, which is also always measured and reported as `sync`")
+                    help="batches per decode group (mode=group: stage 1 runs per bs-16 batch, ONE greedy decode serves "
+                         "this many batches, <= 8 = 128 prefixes) or forwards in flight (mode=streams); 1 = the "
+                         "reference's synchronous forward, which is also always measured and reported as `sync`")
     ap.add_argument("--mode", choices=["group", "streams"], default=os.environ.get("PIO_BENCH_MODE", "group"))
     ap.add_argument("--stage-streams", type=int, default=int(os.environ.get("PIO_BENCH_STAGE_STREAMS", "1")),
                     help="mode=group: model replicas (own ViT workspace, own stream) that stage 1 alternates over")
