@@ -1,0 +1,24 @@
+#!/bin/bash
+# Reproduces profiles/ on a 1-GPU MI355X box (run from the repo root; ~2 minutes):
+#   tools/collect_profiles.sh r01
+# -> profiles/<round>_kernel_stats_sync.csv       rocprofv3 --kernel-trace --stats of `bench.py --in-flight 1`
+#    profiles/<round>_kernel_stats_pipelined.csv  ... of the default bench.py run
+#    profiles/<round>_bench_line.json             the bench line (with cpu_baseline)
+#    profiles/traffic.json                        HBM bytes per launch from two --pmc passes (FETCH_SIZE, WRITE_SIZE; never
+#                                                 combined with other trace domains), summarised by tools/pmc_summary.py
+set -e
+round=${1:-r01}
+R=$(pwd)
+out=$R/gpurun_out/profiles_$round
+mkdir -p $out/sync $out/pipe $out/pmc_f $out/pmc_w
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/sync -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --in-flight 1 > $out/sync/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/pipe -- python3 $R/bench.py --no-cpu-baseline > $out/pipe/bench.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_f -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --in-flight 1 > $out/pmc_f/run.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_w -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --in-flight 1 > $out/pmc_w/run.log 2>&1
+cd $R
+python3 bench.py > $out/bench_line.json 2> $out/bench_line.err
+cp $(find $out/sync -name "*kernel_stats.csv" | head -1) profiles/${round}_kernel_stats_sync.csv
+cp $(find $out/pipe -name "*kernel_stats.csv" | head -1) profiles/${round}_kernel_stats_pipelined.csv
+tail -1 $out/bench_line.json > profiles/${round}_bench_line.json
+python3 tools/pmc_summary.py $(find $out/pmc_f -name "*counter_collection.csv" | head -1) $(find $out/pmc_w -name "*counter_collection.csv" | head -1) profiles/traffic.json | tail -1
