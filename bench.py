@@ -202,11 +202,13 @@ def main():
             for _ in range(9):                      # every pinned staging slot of the ring allocated (one-off, ~ms each)
                 model.preprocess_images(raw)
             torch.cuda.synchronize()
-            tp = time.perf_counter()
-            for _ in range(20):
+            per_call = []
+            for _ in range(20):                     # median of synchronised calls: robust to an allocator / GC hiccup
+                tp = time.perf_counter()
                 dev_imgs = model.preprocess_images(raw)
-            torch.cuda.synchronize()
-            dt_dev = (time.perf_counter() - tp) / 20
+                torch.cuda.synchronize()
+                per_call.append(time.perf_counter() - tp)
+            dt_dev = sorted(per_call)[len(per_call) // 2]
             pil = [Image.fromarray(a) for a in raw]
             tp = time.perf_counter()
             host_imgs = torch.stack([model.image_transforms(im) for im in pil])
