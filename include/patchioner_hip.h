@@ -224,6 +224,12 @@ int64_t pio_bank_rows(pio_handle h);
  * (DINOv2 interpolate_pos_encoding: bicubic, antialias, offset 0).  pos [1+grid*grid, dim] -> out [1+n*n, dim]. */
 int pio_host_interpolate_pos_embed(const float* pos, int32_t grid, int32_t dim, int32_t n, float* out);
 
+/* Host-only: the Pillow resampling table pio_preprocess builds for output samples [first, first + count) of an axis
+ * resized from in_size to out_size (bicubic; Resample.c precompute_coeffs + normalize_coeffs_8bpc).  kk must hold
+ * count * pio_host_pil_ksize(in_size, out_size) int32, bounds 2 * count (min, taps). */
+int pio_host_pil_ksize(int32_t in_size, int32_t out_size);
+int pio_host_pil_table(int32_t in_size, int32_t out_size, int32_t first, int32_t count, int32_t* kk, int32_t* bounds);
+
 #ifdef __cplusplus
 }
 #endif

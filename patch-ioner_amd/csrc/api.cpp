@@ -1019,4 +1019,21 @@ int pio_host_interpolate_pos_embed(const float* pos, int32_t grid, int32_t dim, 
   return PIO_OK;
 }
 
+int pio_host_pil_ksize(int32_t in_size, int32_t out_size) {
+  if (in_size < 1 || out_size < 1) return fail(PIO_ERR_INVALID_ARG, "pio_host_pil_ksize: bad size");
+  PilAxis ax;
+  pil_axis_table(in_size, out_size, 0, 0, ax);
+  return ax.ksize;
+}
+
+int pio_host_pil_table(int32_t in_size, int32_t out_size, int32_t first, int32_t count, int32_t* kk, int32_t* bounds) {
+  if (in_size < 1 || out_size < 1 || first < 0 || count < 0 || first + count > out_size || !kk || !bounds)
+    return fail(PIO_ERR_INVALID_ARG, "pio_host_pil_table: bad argument");
+  PilAxis ax;
+  pil_axis_table(in_size, out_size, first, count, ax);
+  memcpy(kk, ax.kk.data(), ax.kk.size() * sizeof(int32_t));
+  memcpy(bounds, ax.bounds.data(), ax.bounds.size() * sizeof(int32_t));
+  return PIO_OK;
+}
+
 }  // extern "C"

@@ -45,3 +45,27 @@ def test_center_crop_origin_rules():
     assert center_crop_origin(297, 224, 224) == (36, 0)       # 36.5 -> 36
     assert center_crop_origin(200, 150, 224) == (-12, -37)
     assert center_crop_origin(201, 150, 224) == (-11, -37)    # pad 11 left, 12 right
+
+
+def test_c_abi_pillow_tables_are_bit_exact():
+    """The C++ port of Pillow's coefficient builder used by pio_preprocess (api.cpp: pil_axis_table) against the oracle's
+    (itself pinned to Pillow), on the host, no GPU: identical int32 tables for up- and down-scaling, partial windows."""
+    from patchioner_amd import build as pbuild
+    from patchioner_amd._lib import load
+    pbuild.build()
+    lib = load()
+    rng = np.random.RandomState(9)
+    cases = [(640, 298), (480, 224), (100, 280), (17, 224), (1023, 224), (224, 224), (37, 6054), (5, 3), (3, 5)]
+    cases += [(int(rng.randint(2, 2000)), int(rng.randint(2, 800))) for _ in range(20)]
+    for in_size, out_size in cases:
+        kk_ref, b_ref = P.precompute_coeffs(in_size, out_size)
+        ks = lib.pio_host_pil_ksize(in_size, out_size)
+        assert ks == kk_ref.shape[1], (in_size, out_size)
+        first = int(rng.randint(0, out_size))
+        count = int(rng.randint(0, out_size - first + 1))
+        for f, c in ((0, out_size), (first, count)):
+            kk = np.zeros((c, ks), dtype=np.int32)
+            b = np.zeros((c, 2), dtype=np.int32)
+            assert lib.pio_host_pil_table(in_size, out_size, f, c, kk.ctypes.data, b.ctypes.data) == 0
+            assert np.array_equal(kk, kk_ref[f:f + c]) and np.array_equal(b, b_ref[f:f + c]), (in_size, out_size, f, c)
+    assert lib.pio_host_pil_table(10, 5, 3, 3, None, None) < 0
