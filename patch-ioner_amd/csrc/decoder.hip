@@ -126,7 +126,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? PIO_DEC_GEMM_WAVES : 1) void k
   if constexpr (XLDS) {
     // <= 16 prefixes: the workgroup's slice of X (16 x 768) goes through LDS with fully coalesced loads instead of
     // 16-row x 64-B fragment-shaped ones (rows padded to 772 floats: the 16 rows of a fragment read fall on 16
-    // distinct 16-B slots).  Same values, same MFMA order: bit-identical; 0.25-0.5 us per kernel.
+    // distinct 16-B slots).  Same values, same MFMA order: bit-identical; 0.25-0.5 us per kernel.  (Above 16 prefixes,
+    // one row group at a time with the next one prefetched: two barriers per group and a staging array that hipcc keeps
+    // in scratch made it 2x slower -- 19.9 vs 9.9 us for qkv at 64 prefixes; not kept.)
     float4 xs[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
