@@ -53,6 +53,9 @@ namespace pio {
 #ifndef PIO_LMHEAD_FILTER     // greedy ids through the fp16 filter + exact re-evaluation (log-probabilities: exact head)
 #define PIO_LMHEAD_FILTER 1
 #endif
+#ifndef PIO_DEC_TILED           // above 16 prefixes: k_dec_gemm_b (X tiles through LDS) instead of k_dec_gemm
+#define PIO_DEC_TILED 1
+#endif
 #ifndef PIO_DEC_XLDS
 #define PIO_DEC_XLDS 1
 #endif
@@ -64,6 +67,7 @@ namespace pio {
 #endif
 
 static constexpr int DEC_MAX_COLGROUPS = 64;   // split-K counters / slabs are sized for Nout <= 1024
+static constexpr size_t DEC_SPLITK_WS_FLOATS = (size_t)64 * 4 * 8 * 256;   // api.cpp: splitk_ws
 
 enum DecEpi { DE_STORE = 0, DE_RESID = 1, DE_GELU = 2, DE_EMBED = 3, DE_ARGMAX = 4 };
 
@@ -459,11 +463,235 @@ static hipError_t dec_gemm_rg(const float* W, const float* X, int N, int Nout, i
   return hipGetLastError();
 }
 
+
+typedef __attribute__((address_space(3))) void* dec_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* dec_gbl_ptr_t;
+
+// ---- decoder GEMMs above 16 prefixes: X tiles through LDS -----------------------------------------------------
+// k_dec_gemm re-reads ALL rows of X per 16 output columns in fragment-shaped loads: 442 KB per workgroup at 128
+// prefixes, and a CU ingests only ~50 KB/us through L2: every layer GEMM took 16-21 us whatever its grid (48 .. 192
+// workgroups), against ~3 us of fp32 MFMA work chip-wide.  Here a workgroup owns [16 RGB rows][16 NCG columns] and the
+// whole K = 768 (KS > 1: one 768-slice of K = 3072, met through the same in-launch ticket as k_dec_gemm); wave
+// (cg, kw) multiplies column group cg with the kw-th 16 k's of every 64-k chunk.  X chunks ([16 RGB][64] fp32, 16-B
+// slots XOR-swizzled with the row as in k_lmhead_wide) stream through an LDS ring by LDS-DMA, shared by all 4 NCG
+// waves; W goes straight to registers (12 x 16 B per lane).  Both are inline asm with hand-counted vmcnt (see
+// k_lmhead_wide for why); chunk q is consumed while the later chunks are in flight.  Tile shapes are picked per GEMM
+// and prefix count from tools/microbench/dec_bench.hip (128 prefixes: 32 x 48 for qkv / fc, 32 x 16 for proj,
+// 64 x 32 x 4 k-slices for fc2: 12.6 / 6.3 / 12.9 / 15.4 us against 16.5 / 16.3 / 17.0 / 21.1).
+// Measured and dropped: splitting K = 768 as well (bricks of 64 x 64 x 128..384 with the ticket) -- the ticket's
+// serial tail (store -> write-back -> cross-XCD atomic -> invalidate -> slab re-read) costs 5-14 us on this part,
+// as much as the smaller bricks save.
+//   grid = (Nout / (16 NCG), KS, ceil(N / (16 RGB))), 256 NCG threads.
+template <int C> __device__ __forceinline__ void dec_wait_vm(f32x4& w) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w) : "n"(C) : "memory");
+}
+template <int RGB, int NCG, int KS, int EPI, int LN>
+__global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_b(const float* __restrict__ W, const float* __restrict__ X, int N, int Nout, int K,
+                                                             const float* __restrict__ bias, float* out,
+                                                             const float* __restrict__ cvec, float eps, float* ws, unsigned* cnt) {
+  static_assert(!(LN && KS > 1), "LayerNorm row sums need the whole row in one workgroup");
+  static_assert(RGB == 1 || RGB == 2 || RGB == 4, "row groups per workgroup");
+  constexpr int NW = 4 * NCG, CH = 64, NQ = 12, ROWS = 16 * RGB, XB = ROWS * CH;
+  constexpr int RB = RGB == 4 ? 8 : 12;                     // ring depth (RB == NQ: every chunk has its own buffer)
+  constexpr int PIECES = 4 * RGB;                           // 1-KiB LDS-DMA pieces per chunk
+  constexpr int NISS = PIECES < NW ? PIECES : NW;           // waves that issue them
+  constexpr int DPW = PIECES / NISS;
+  static_assert(DPW * NISS == PIECES, "pieces must divide among the issuing waves");
+  extern __shared__ __attribute__((aligned(16))) float lsm[];      // ring [RB][ROWS][64]; afterwards partial tiles [NW][RGB][256]
+  __shared__ float s_sum[LN ? 4 : 1][ROWS], s_sq[LN ? 4 : 1][ROWS];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int cg = wid >> 2, kw = wid & 3;
+  const int row0 = blockIdx.z * ROWS;
+  const int kbase = blockIdx.y * (NQ * CH);
+  const int j = (blockIdx.x * NCG + cg) * 16 + li;
+  const float* wp = W + (size_t)j * K + kbase + 16 * kw + 4 * kq;
+  static_assert(NISS == NW || (DPW == 1 && RB == NQ), "see the wait in PIO_BSTEP");
+  const bool issuer = NISS == NW || wid < NISS;             // wave-uniform
+  f32x4 w[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const float* _p = wp + q * CH;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[q]) : "v"(_p) : "memory");
+  }
+  // LDS-DMA pieces of a chunk: piece t = wid + NISS i covers rows 4t .. 4t+3 (1 KiB); lane l fills slot (l & 15) of
+  // row 4t + (l >> 4) and therefore fetches source slot (l & 15) ^ (row & 15).
+  uint32_t xoff[DPW];
+#pragma unroll
+  for (int i = 0; i < DPW; ++i) {
+    const int row = (4 * (wid + NISS * i) + (lane >> 4)) & (ROWS - 1);
+    const int rc = row0 + row < N ? row0 + row : N - 1;
+    xoff[i] = (uint32_t)rc * K + kbase + 4 * ((lane & 15) ^ (row & 15));
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(dec_lds_ptr_t)lsm + (uint32_t)wid * 1024u;
+#define PIO_XISSUE(q)                                                                                          \
+  do {                                                                                                         \
+    if (issuer) {                                                                                              \
+      _Pragma("unroll") for (int i = 0; i < DPW; ++i) {                                                        \
+        const float* _g = X + (q) * CH + xoff[i];                                                              \
+        const uint32_t _l = lds0 + (uint32_t)((((q) % RB) * XB + i * NISS * 256) * 4);                         \
+        uint32_t _keep;                                                                                        \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(_keep) : "v"(_g), "s"(_l) : "memory");                                            \
+      }                                                                                                        \
+    }                                                                                                          \
+  } while (0)
+#pragma unroll
+  for (int q = 0; q < RB; ++q) PIO_XISSUE(q);
+  f32x4 acc[RGB];
+  float sx[RGB], sq[RGB];
+#pragma unroll
+  for (int g = 0; g < RGB; ++g) { acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; sx[g] = 0.f; sq[g] = 0.f; }
+  // vm queue of an issuing wave: W(0..11) | X(0) .. X(RB-1) | X(RB) .. X(11) (X(q+RB-1) is issued in step q >= 1).
+  // At the wait of step q the youngest chunk issued is min(11, RB - 1 + max(q - 1, 0)); everything up to chunk q has
+  // landed once at most DPW * (that - q) operations are outstanding.  A wave that issues no pieces (NISS < NW: then
+  // DPW == 1 and RB == NQ) has only its weight loads in the queue and needs W(q): at most 11 - q outstanding -- the
+  // same immediate, so the wait is branch-free (hipcc, given two asm waits on one register set in the two arms of a
+  // branch, hoists a copy of the registers above them: caught by tools/microbench/asm_load_audit.py).
+#define PIO_BSTEP(q)                                                                                           \
+  do {                                                                                                         \
+    constexpr int _y0 = RB - 1 + ((q) > 1 ? (q) - 1 : 0);                                                      \
+    constexpr int _young = _y0 < NQ - 1 ? _y0 : NQ - 1;                                                        \
+    dec_wait_vm<DPW * (_young - (q))>(w[q]);                                                                   \
+    __builtin_amdgcn_s_barrier();      /* chunk q landed in every wave; every wave is done with chunk q-1 */    \
+    if ((q) >= 1 && (q) + RB - 1 < NQ) PIO_XISSUE((q) + RB - 1);                                               \
+    const float* _xb = lsm + ((q) % RB) * XB;                                                                  \
+    _Pragma("unroll") for (int g = 0; g < RGB; ++g) {                                                          \
+      const float4 xf = *(const float4*)(_xb + (16 * g + li) * CH + (((4 * kw + kq) ^ li) << 2));              \
+      acc[g] = mfma16f(xf.x, w[q][0], acc[g]);                                                                 \
+      acc[g] = mfma16f(xf.y, w[q][1], acc[g]);                                                                 \
+      acc[g] = mfma16f(xf.z, w[q][2], acc[g]);                                                                 \
+      acc[g] = mfma16f(xf.w, w[q][3], acc[g]);                                                                 \
+      if (LN && cg == 0) {                                                                                     \
+        sx[g] += (xf.x + xf.y) + (xf.z + xf.w);                                                                \
+        sq[g] += (xf.x * xf.x + xf.y * xf.y) + (xf.z * xf.z + xf.w * xf.w);                                    \
+      }                                                                                                        \
+    }                                                                                                          \
+  } while (0)
+  PIO_BSTEP(0); PIO_BSTEP(1); PIO_BSTEP(2); PIO_BSTEP(3); PIO_BSTEP(4); PIO_BSTEP(5);
+  PIO_BSTEP(6); PIO_BSTEP(7); PIO_BSTEP(8); PIO_BSTEP(9); PIO_BSTEP(10); PIO_BSTEP(11);
+#undef PIO_BSTEP
+#undef PIO_XISSUE
+  const float bj = bias[j];
+  const float cj = LN ? cvec[j] : 0.f;
+  if (LN && cg == 0) {
+#pragma unroll
+    for (int g = 0; g < RGB; ++g) {
+      float tx = sx[g], tq = sq[g];
+      tx += __shfl_xor(tx, 16); tx += __shfl_xor(tx, 32);
+      tq += __shfl_xor(tq, 16); tq += __shfl_xor(tq, 32);
+      if (kq == 0) { s_sum[kw][g * 16 + li] = tx; s_sq[kw][g * 16 + li] = tq; }
+    }
+  }
+  __syncthreads();                                  // every wave is done with the ring: reuse it for the partial tiles
+#pragma unroll
+  for (int g = 0; g < RGB; ++g) *(f32x4*)(lsm + ((wid * RGB + g) * 64 + lane) * 4) = acc[g];
+  __syncthreads();
+  // wave (cg, kw < RGB) finishes row group g = kw of its column group: the four k-quarter partials, in order
+  const int g = kw;
+  const bool fin = kw < RGB;                        // wave-uniform
+  f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (fin) {
+    s = *(const f32x4*)(lsm + (((cg * 4 + 0) * RGB + g) * 64 + lane) * 4);
+#pragma unroll
+    for (int k2 = 1; k2 < 4; ++k2) s += *(const f32x4*)(lsm + (((cg * 4 + k2) * RGB + g) * 64 + lane) * 4);
+  }
+  if constexpr (KS > 1) {
+    constexpr int NP = NCG * RGB;                   // finished (column group, row group) pairs per workgroup
+    const int tile = blockIdx.z * gridDim.x + blockIdx.x;
+    float* tbase = ws + (size_t)tile * KS * NP * 256;
+    const int pr = cg * RGB + g;
+    if (fin) *(f32x4*)(tbase + ((size_t)blockIdx.y * NP + pr) * 256 + lane * 4) = s;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its stores
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the release's write-back has completed
+      const unsigned t = __hip_atomic_fetch_add(cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == (unsigned)(KS - 1));
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    }
+    __syncthreads();
+    if (fin) {
+      s = *(const f32x4*)(tbase + ((size_t)0 * NP + pr) * 256 + lane * 4);
+#pragma unroll
+      for (int y = 1; y < KS; ++y) s += *(const f32x4*)(tbase + ((size_t)y * NP + pr) * 256 + lane * 4);
+    }
+  }
+  if (!fin) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = g * 16 + 4 * kq + i, n = row0 + rr;
+    if (n >= N) continue;
+    float v;
+    if (LN) {   // s_i <- r_n (s_i - mu_n c_j) + d_j
+      const float tx = (s_sum[0][rr] + s_sum[1][rr]) + (s_sum[2][rr] + s_sum[3][rr]);
+      const float tq = (s_sq[0][rr] + s_sq[1][rr]) + (s_sq[2][rr] + s_sq[3][rr]);
+      const float mu = tx / (float)K;
+      const float var = fmaxf(tq / (float)K - mu * mu, 0.f);
+      v = rsqrtf(var + eps) * (s[i] - mu * cj) + bj;
+    } else {
+      v = s[i] + bj;
+    }
+    float* o = out + (size_t)n * Nout + j;
+    if constexpr (EPI == DE_STORE) *o = v;
+    else if constexpr (EPI == DE_RESID) *o += v;
+    else if constexpr (EPI == DE_GELU) *o = gelu_new(v);
+  }
+}
+
+template <int RGB, int NCG, int KS, int EPI, int LN>
+static hipError_t dec_gemm_b_launch(const float* W, const float* X, int N, int Nout, int K, const float* bias, float* out,
+                                    const float* cvec, float eps, float* ws, unsigned* cnt, hipStream_t s) {
+  const dim3 grid(Nout / (16 * NCG), KS, ceil_div(N, 16 * RGB));
+  if (K != KS * 768 || Nout % (16 * NCG) != 0 || N < 1 || N > 128) return hipErrorInvalidValue;
+  if (KS > 1 && ((int)(grid.x * grid.z) > DEC_MAX_COLGROUPS || (size_t)grid.x * grid.z * KS * NCG * RGB * 256 > DEC_SPLITK_WS_FLOATS || !ws || !cnt))
+    return hipErrorInvalidValue;
+  constexpr int RB = RGB == 4 ? 8 : 12;
+  constexpr int ring = RB * 16 * RGB * 64 * 4, tiles = 4 * NCG * RGB * 1024;
+  constexpr int smem = ring > tiles ? ring : tiles;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_dec_gemm_b<RGB, NCG, KS, EPI, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_dec_gemm_b<RGB, NCG, KS, EPI, LN>), grid, dim3(256 * NCG), smem, s, W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt);
+  return hipGetLastError();
+}
+
 // K = 768 (4 waves x 12 chunks), 512 (4 x 8) or 3072 (4 workgroups x 4 waves x 12, split-K with `ws` / `cnt`)
 template <int EPI, int LN>
 static hipError_t dec_gemm(const float* W, const float* X, int N, int Nout, int K, const float* bias, float* out,
                            const float* extra, const float* cvec, float eps, float* ws, unsigned* cnt, hipStream_t s) {
   if (N < 1 || N > 128) return hipErrorInvalidValue;
+  if constexpr (PIO_DEC_TILED != 0 && (EPI == DE_STORE || EPI == DE_RESID || EPI == DE_GELU)) {
+    const int rg = ceil_div(N, 16);
+    if (rg >= 2 && K == 768 && Nout % 48 == 0) {
+      const bool wide = Nout >= 2304;       // qkv / fc: 48 (32) columns per workgroup; proj: 16
+      if (rg > 4) return wide ? dec_gemm_b_launch<2, 3, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s)
+                              : dec_gemm_b_launch<2, 1, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
+      if (rg > 2) return wide ? dec_gemm_b_launch<1, 3, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s)
+                              : dec_gemm_b_launch<1, 1, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
+      return wide ? dec_gemm_b_launch<1, 2, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s)
+                  : dec_gemm_b_launch<1, 1, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
+    }
+    if constexpr (EPI == DE_RESID && !LN) {
+      if (rg >= 2 && K == 3072 && Nout % 32 == 0 && Nout <= 32 * (DEC_MAX_COLGROUPS / 2) && ws != nullptr && cnt != nullptr) {
+        if (rg > 4) return dec_gemm_b_launch<4, 2, 4, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
+        if (rg > 2) return dec_gemm_b_launch<2, 2, 4, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
+        return dec_gemm_b_launch<1, 2, 4, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
+      }
+    }
+  }
   if (K == 768) return dec_gemm_rg<12, 1, EPI, LN>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);
   if (K == 512) return dec_gemm_rg<8, 1, EPI, LN>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);
   if (K == 384) return dec_gemm_rg<6, 1, EPI, LN>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);   // ViT-S prefix
@@ -485,9 +713,6 @@ hipError_t decoder_init() { return hipSuccess; }   // no function attributes nee
 // traffic / 4, no cross-wave reduction.  W streams HBM -> registers, three chunk sets deep (two chunks ahead).
 // Numerics are BIT-IDENTICAL to k_dec_gemm<.., DE_ARGMAX, LN>: the same lane <-> (column, k) mapping, the same two
 // MFMA chains per 192-k slice, slices added in order, LayerNorm row sums built per slice in the same order.
-typedef __attribute__((address_space(3))) void* dec_lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* dec_gbl_ptr_t;
-
 template <int RG>
 __global__ __launch_bounds__(256, 2) void k_lmhead_wide(const float* __restrict__ W, const float* __restrict__ X, int N, int V,
                                                         const float* __restrict__ dvec, const float* __restrict__ cvec,

@@ -16,7 +16,7 @@ for n,l in enumerate(lines):
     t=l.strip()
     if not t or t.startswith(';') or t.startswith('.'): continue
     if t.startswith('global_load_dwordx4'):
-        m=re.match(r'global_load_dwordx4 v\[(\d+):(\d+)\], (v\[\d+:\d+\])', t)
+        m=re.match(r'global_load_dwordx4 v\[(\d+):(\d+)\], (v\[\d+:\d+\]|v\d+)', t)
         for r in regs_in(m.group(3)):
             if r in pending: viol.append((n,t,'addr uses pending reg v%d'%r))
         vmops.append(n)

@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
   const int E = 768, V = 50257, S = 32, heads = 4;
   float *w_qkv, *w_proj, *w_fc, *w_fc2, *w_head, *x, *qkv, *att, *hid, *part, *bias, *cvec, *kc, *vc, *wte, *wpe;
   int32_t* ids; float* lp; float* ws; unsigned* cnt;
-  hipMalloc(&ws, 64 * 4 * 4 * 256 * 4); hipMalloc(&cnt, 256); hipMemset(cnt, 0, 256);
+  hipMalloc(&ws, (size_t)256 * 16 * 8 * 256 * 4); hipMalloc(&cnt, 4096); hipMemset(cnt, 0, 4096);
   CK(hipMalloc(&w_qkv, (size_t)3 * E * E * 4)); CK(hipMalloc(&w_proj, (size_t)E * E * 4));
   CK(hipMalloc(&w_fc, (size_t)4 * E * E * 4)); CK(hipMalloc(&w_fc2, (size_t)4 * E * E * 4));
   CK(hipMalloc(&w_head, (size_t)V * E * 4)); CK(hipMalloc(&wte, (size_t)V * E * 4)); CK(hipMalloc(&wpe, (size_t)1024 * E * 4));
@@ -66,10 +66,64 @@ int main(int argc, char** argv) {
       printf("graph x200 %s  %7.2f us per node\n", which == 0 ? "empty" : "touch", time_chain([&] { hipGraphLaunch(ex, s); }, 20) / 200.f);
     }
   }
-  printf("qkv  (LN, store)   %7.2f us\n", time_chain([&] { dec_gemm<DE_STORE, 1>(w_qkv, x, N, 3 * E, E, bias, qkv, nullptr, cvec, 1e-5f, nullptr, nullptr, s); }));
+  printf("qkv  (LN, store)   %7.2f us   old %7.2f us\n", time_chain([&] { dec_gemm<DE_STORE, 1>(w_qkv, x, N, 3 * E, E, bias, qkv, nullptr, cvec, 1e-5f, nullptr, nullptr, s); }), time_chain([&] { dec_gemm_rg<12, 1, DE_STORE, 1>(w_qkv, x, N, 3 * E, E, bias, qkv, nullptr, cvec, 1e-5f, nullptr, nullptr, s); }));
   printf("attention pos=15   %7.2f us\n", time_chain([&] { hipLaunchKernelGGL(k_dec_attention, dim3(N * heads), dim3(256), 0, s, qkv, kc, vc, E, heads, 15, S, att); }));
   printf("attention pos=29   %7.2f us\n", time_chain([&] { hipLaunchKernelGGL(k_dec_attention, dim3(N * heads), dim3(256), 0, s, qkv, kc, vc, E, heads, 29, S, att); }));
   printf("proj (resid)       %7.2f us\n", time_chain([&] { dec_gemm<DE_RESID, 0>(w_proj, att, N, E, E, bias, x, nullptr, nullptr, 0.f, ws, cnt, s); }));
+  if (N > 16) {   // split-K sensitivity of the non-LN GEMMs (X traffic per workgroup / workgroup count)
+    printf("proj KS2 CPW6      %7.2f us\n", time_chain([&] { dec_gemm_rg<6, 2, DE_RESID, 0>(w_proj, att, N, E, E, bias, x, nullptr, nullptr, 0.f, ws, cnt, s); }));
+    printf("proj KS3 CPW4      %7.2f us\n", time_chain([&] { dec_gemm_rg<4, 3, DE_RESID, 0>(w_proj, att, N, E, E, bias, x, nullptr, nullptr, 0.f, ws, cnt, s); }));
+    printf("proj KS6 CPW2      %7.2f us\n", time_chain([&] { dec_gemm_rg<2, 6, DE_RESID, 0>(w_proj, att, N, E, E, bias, x, nullptr, nullptr, 0.f, ws, cnt, s); }));
+    printf("fc2 KS8 CPW6       %7.2f us\n", time_chain([&] { dec_gemm_rg<6, 8, DE_RESID, 0>(w_fc2, hid, N, E, 4 * E, bias, x, nullptr, nullptr, 0.f, ws, cnt, s); }));
+    printf("fc2 KS12 CPW4      %7.2f us\n", time_chain([&] { dec_gemm_rg<4, 12, DE_RESID, 0>(w_fc2, hid, N, E, 4 * E, bias, x, nullptr, nullptr, 0.f, ws, cnt, s); }));
+  }
+  if (N > 16) {   // X tiles through LDS (k_dec_gemm_b): shape sweep
+    float* ref; float* got; CK(hipMalloc(&ref, (size_t)N * 4 * E * 4)); CK(hipMalloc(&got, (size_t)N * 4 * E * 4));
+    std::vector<float> hr((size_t)N * 4 * E), hg((size_t)N * 4 * E);
+    auto cmp = [&](const char* what, int cols) {
+      hipDeviceSynchronize();
+      hipMemcpy(hr.data(), ref, (size_t)N * cols * 4, hipMemcpyDeviceToHost); hipMemcpy(hg.data(), got, (size_t)N * cols * 4, hipMemcpyDeviceToHost);
+      double md = 0, mr = 0; for (size_t i = 0; i < (size_t)N * cols; ++i) { md = fmax(md, fabs((double)hr[i] - hg[i])); mr = fmax(mr, fabs((double)hr[i])); }
+      printf("   check %-10s max|diff| %.3g  (max|ref| %.3g)\n", what, md, mr);
+    };
+    dec_gemm_rg<12, 1, DE_STORE, 1>(w_qkv, x, N, 3 * E, E, bias, ref, nullptr, cvec, 1e-5f, nullptr, nullptr, s);
+    dec_gemm_rg<12, 1, DE_GELU, 1>(w_fc, x, N, 4 * E, E, bias, ref, nullptr, cvec, 1e-5f, nullptr, nullptr, s);
+    dec_gemm_rg<12, 1, DE_STORE, 0>(w_proj, att, N, E, E, bias, ref, nullptr, nullptr, 0.f, nullptr, nullptr, s);
+    hipMemset(ref, 0, (size_t)N * E * 4); hipMemset(got, 0, (size_t)N * E * 4);
+    dec_gemm_rg<12, 4, DE_RESID, 0>(w_fc2, hid, N, E, 4 * E, bias, ref, nullptr, nullptr, 0.f, ws, cnt, s);
+    dec_gemm_rg<12, 1, DE_STORE, 1>(w_qkv, x, N, 3 * E, E, bias, ref, nullptr, cvec, 1e-5f, nullptr, nullptr, s);
+    CK((dec_gemm_b_launch<4, 2, 1, DE_STORE, 1>(w_qkv, x, N, 3 * E, E, bias, got, cvec, 1e-5f, ws, cnt, s))); cmp("b qkv 4,2", 3 * E);
+    CK((dec_gemm_b_launch<2, 3, 1, DE_STORE, 1>(w_qkv, x, N, 3 * E, E, bias, got, cvec, 1e-5f, ws, cnt, s))); cmp("b qkv 2,3", 3 * E);
+    CK((dec_gemm_b_launch<1, 2, 1, DE_STORE, 1>(w_qkv, x, N, 3 * E, E, bias, got, cvec, 1e-5f, ws, cnt, s))); cmp("b qkv 1,2", 3 * E);
+    dec_gemm_rg<12, 1, DE_STORE, 0>(w_proj, att, N, E, E, bias, ref, nullptr, nullptr, 0.f, nullptr, nullptr, s);
+    CK((dec_gemm_b_launch<2, 1, 1, DE_STORE, 0>(w_proj, att, N, E, E, bias, got, nullptr, 0.f, ws, cnt, s))); cmp("b proj 2,1", E);
+    hipMemset(ref, 0, (size_t)N * E * 4); hipMemset(got, 0, (size_t)N * E * 4);
+    dec_gemm_rg<12, 4, DE_RESID, 0>(w_fc2, hid, N, E, 4 * E, bias, ref, nullptr, nullptr, 0.f, ws, cnt, s);
+    CK((dec_gemm_b_launch<2, 3, 4, DE_RESID, 0>(w_fc2, hid, N, E, 4 * E, bias, got, nullptr, 0.f, ws, cnt, s))); cmp("b fc2 2,3x4", E);
+#define TB(label, R, C, KSV, EPIV, LNV, WW, XX, NO, KK, OUT, CV) \
+    printf("b %-8s R%d C%d KS%d %7.2f us  (%d wg)\n", label, R, C, KSV, time_chain([&] { dec_gemm_b_launch<R, C, KSV, EPIV, LNV>(WW, XX, N, NO, KK, bias, OUT, CV, 1e-5f, ws, cnt, s); }), (NO / (16 * C)) * KSV * ((N + 16 * R - 1) / (16 * R)))
+    TB("qkv", 4, 2, 1, DE_STORE, 1, w_qkv, x, 3 * E, E, qkv, cvec);
+    TB("qkv", 2, 3, 1, DE_STORE, 1, w_qkv, x, 3 * E, E, qkv, cvec);
+    TB("qkv", 2, 2, 1, DE_STORE, 1, w_qkv, x, 3 * E, E, qkv, cvec);
+    TB("qkv", 2, 1, 1, DE_STORE, 1, w_qkv, x, 3 * E, E, qkv, cvec);
+    TB("qkv", 1, 3, 1, DE_STORE, 1, w_qkv, x, 3 * E, E, qkv, cvec);
+    TB("qkv", 1, 2, 1, DE_STORE, 1, w_qkv, x, 3 * E, E, qkv, cvec);
+    TB("proj", 4, 1, 1, DE_RESID, 0, w_proj, att, E, E, x, nullptr);
+    TB("proj", 2, 1, 1, DE_RESID, 0, w_proj, att, E, E, x, nullptr);
+    TB("proj", 1, 1, 1, DE_RESID, 0, w_proj, att, E, E, x, nullptr);
+    TB("fc", 4, 2, 1, DE_GELU, 1, w_fc, x, 4 * E, E, hid, cvec);
+    TB("fc", 2, 3, 1, DE_GELU, 1, w_fc, x, 4 * E, E, hid, cvec);
+    TB("fc", 2, 2, 1, DE_GELU, 1, w_fc, x, 4 * E, E, hid, cvec);
+    TB("fc", 1, 3, 1, DE_GELU, 1, w_fc, x, 4 * E, E, hid, cvec);
+    TB("fc", 1, 2, 1, DE_GELU, 1, w_fc, x, 4 * E, E, hid, cvec);
+    TB("fc2", 4, 2, 4, DE_RESID, 0, w_fc2, hid, E, 4 * E, x, nullptr);
+    TB("fc2", 2, 3, 4, DE_RESID, 0, w_fc2, hid, E, 4 * E, x, nullptr);
+    TB("fc2", 2, 2, 4, DE_RESID, 0, w_fc2, hid, E, 4 * E, x, nullptr);
+    TB("fc2", 2, 1, 4, DE_RESID, 0, w_fc2, hid, E, 4 * E, x, nullptr);
+    TB("fc2", 1, 2, 4, DE_RESID, 0, w_fc2, hid, E, 4 * E, x, nullptr);
+    TB("fc2", 1, 1, 4, DE_RESID, 0, w_fc2, hid, E, 4 * E, x, nullptr);
+    CK(hipMemcpy(x, h.data(), (size_t)N * E * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(hid, h.data(), (size_t)N * 4 * E * 4, hipMemcpyHostToDevice));
+  }
   printf("fc   (LN, gelu)    %7.2f us\n", time_chain([&] { dec_gemm<DE_GELU, 1>(w_fc, x, N, 4 * E, E, bias, hid, nullptr, cvec, 1e-5f, nullptr, nullptr, s); }));
   printf("fc2  (resid)       %7.2f us\n", time_chain([&] { dec_gemm<DE_RESID, 0>(w_fc2, hid, N, E, 4 * E, bias, x, nullptr, nullptr, 0.f, ws, cnt, s); }));
   printf("lm head (argmax)   %7.2f us\n", time_chain([&] { launch_lmhead(w_head, x, N, V, E, bias, cvec, 1e-5f, part, &nblk, s); }, 50));
