@@ -28,7 +28,7 @@ MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
-def build_models(device_index: int, count: int, max_prefixes: int = 64):
+def build_models(device_index: int, count: int, max_prefixes: int = 64, max_batch: int = BATCH):
     """`count` identical model instances (own workspaces / decode graphs / bank copy each) for `count` batches in flight."""
     from patchioner_amd import Patchioner, weights as W
     g = torch.Generator(device="cuda").manual_seed(6)
@@ -39,7 +39,7 @@ def build_models(device_index: int, count: int, max_prefixes: int = 64):
     cfg = {"decap_weights": W.synth_decap(3), "dino_weights": W.synth_dinov2(1), "memory_bank": bank,
            "prefix_size": 768, "linear_talk2dino": False, "support_memory_size": BANK_ROWS,
            "dino_model": "dinov2_vitb14_reg", "normalize": True, "resize_dim": CROP, "crop_dim": CROP,
-           "max_batch": BATCH, "max_prefixes": max_prefixes}
+           "max_batch": max_batch, "max_prefixes": max_prefixes}
     models = [Patchioner.from_config(cfg, device="cuda:%d" % device_index) for _ in range(count)]
     del bank
     torch.cuda.empty_cache()
@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--mode", choices=["group", "streams"], default=os.environ.get("PIO_BENCH_MODE", "group"))
     ap.add_argument("--stage-streams", type=int, default=int(os.environ.get("PIO_BENCH_STAGE_STREAMS", "1")),
                     help="mode=group: model replicas (own ViT workspace, own stream) that stage 1 alternates over")
+    ap.add_argument("--vit-batches", type=int, default=int(os.environ.get("PIO_BENCH_VIT_BATCHES", "2")),
+                    help="mode=group: consecutive bs-16 batches that share one ViT launch (1 = a launch per batch)")
     args = ap.parse_args()
 
     from patchioner_amd import dist as pdist
@@ -108,8 +110,9 @@ def main():
 
     P = max(1, args.in_flight)
     S = max(1, args.stage_streams)
+    VB = max(1, min(args.vit_batches, P)) if args.mode == "group" else 1
     models = build_models(local, P if args.mode == "streams" else S,
-                          max_prefixes=min(128, max(64, BATCH * P)) if args.mode == "group" else 64)
+                          max_prefixes=min(128, max(64, BATCH * P)) if args.mode == "group" else 64, max_batch=BATCH * VB)
     model = models[0]
     streams = [torch.cuda.Stream() for _ in range(P)]
     imgs, traces = make_inputs()
@@ -122,7 +125,7 @@ def main():
     pipe = None
     if args.mode == "group" and P > 1:
         from patchioner_amd.pipeline import TraceCaptionPipeline
-        pipe = TraceCaptionPipeline(model, group_batches=P, stage_replicas=models[1:S],
+        pipe = TraceCaptionPipeline(model, group_batches=P, stage_replicas=models[1:S], vit_batches=VB,
                                     stage_cus=int(os.environ.get("PIO_STAGE_CUS", "0")) or None,
                                     decode_cus=int(os.environ.get("PIO_DECODE_CUS", "0")) or None)
 
@@ -246,7 +249,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
             "config": {"workload": "talk2dino_decap_COCO, ViT-B/14-reg 224^2, batch 16/GPU, caption_from=patches "
                                    "(one 16-patch trace region per image), bank 591753x768 fp32, 30-step greedy decode",
-                       "global_batch": BATCH * world, "parallelism": "dp%d (image shards, ids all-gather)" % world, "batches_in_flight_per_gpu": P,
+                       "global_batch": BATCH * world, "parallelism": "dp%d (image shards, ids all-gather)" % world, "batches_in_flight_per_gpu": P, "batches_per_vit_launch": VB,
                        "pipelining": "none" if P == 1 else ("one decode per %d batches, overlapped with the next batches' ViT on %d stream(s)" % (P, S)
                                                            if args.mode == "group" else "%d forwards on %d streams" % (P, P))},
             "roofline": {"kernel": "k_vit_gemm (fp16 MFMA 32x32x16, 48+1 launches/step)", "bound": "mfma",

@@ -11,8 +11,11 @@ per microsecond overall).  So this driver
   stage 2 (stream B): ONE greedy decode for the whole group (up to 64 prefixes = 4 batches of 16),
 
 and stage 2 of group g runs while stage 1 of group g+1 is being computed (small decode kernels fill the CUs
-the big ViT GEMMs leave).  Every batch is still a bs-16 ViT pass and the token ids are bit-identical to the
-synchronous path (the decoder is exact fp32 and row-independent); captions come back per batch, in order.
+the big ViT GEMMs leave).  ``vit_batches`` consecutive batches may also share one ViT launch (the backbone costs
+118 us per image at 16 images per launch, 86 us at 48 and more: fewer GEMM tails and launch gaps; the model's
+``max_batch`` must cover them).  The token ids are bit-identical to the synchronous path either way (every ViT
+output element is computed in the same order whatever the launch holds; the decoder is exact fp32 and
+row-independent); captions come back per batch, in order.
 """
 from __future__ import annotations
 
@@ -41,13 +44,16 @@ class TraceCaptionPipeline:
     ``traces=None`` captions the CLS token instead (caption_from=cls)."""
 
     def __init__(self, model, group_batches: int = 4, use_attention_tracing: bool = False, steps: int = 30,
-                 stage_replicas: Sequence = (), stage_cus: Optional[int] = None, decode_cus: Optional[int] = None):
+                 stage_replicas: Sequence = (), stage_cus: Optional[int] = None, decode_cus: Optional[int] = None,
+                 vit_batches: int = 1):
         """``stage_replicas``: further Patchioner instances holding the SAME weights (each has its own ViT
         workspace); stage 1 of consecutive batches then alternates over the replicas, each on its own stream,
         so that one batch's GEMM tails, epilogues and launch gaps are filled by the other's kernels."""
         self.m, self.eng = model, model.engine
         self.stage_models = [model] + list(stage_replicas)
         self.group_batches = group_batches
+        self.vit_batches = max(1, int(vit_batches))
+        self._held: List = []             # batches waiting for their shared ViT launch
         # batches whose embeddings share one projection call.  2 would make one 32-query bank pass of two batches
         # (0.44 instead of 0.56 ms per batch for the projection alone) -- measured: no change in pipelined throughput
         # (5.24 k vs 5.27 k captions/s), so the batches are projected as they arrive.
@@ -94,28 +100,34 @@ class TraceCaptionPipeline:
         self._raw_streams = []
 
     # ---- stage 1: everything up to the decoder prefix, on stream A ------------------------------------
-    def _stage(self, g: _Group, imgs: torch.Tensor, traces) -> None:
+    def _stage(self, g: _Group, held: List) -> None:
+        """One ViT launch for the held batches, then per batch: read-out, region mean, projection."""
         k = self._nstaged % len(self.stage_models)
         self._nstaged += 1
         m, stream = self.stage_models[k], self.stage_streams[k]
         eng = m.engine
         with torch.cuda.stream(stream):
-            tokens, qkv = eng.vit_forward(imgs, want_qkv=traces is not None and self.use_attention_tracing)
-            if traces is None:
-                emb = tokens[:, 0].contiguous()
-            else:
-                grids = eng.trace_grids(traces).view(imgs.shape[0], -1)
-                if self.use_attention_tracing:
-                    self_attn, _, _, _ = eng.cls_attention(qkv, tokens)
-                    grids = self_attn * grids
-                emb = eng.region_reduce(tokens, grids, None, 1.0 / m.num_patch_tokens)
-            n = emb.shape[0]
-            g.rows += n
-            g.counts.append(n)
-            g.pending.append((emb, stream, m))
-            # the memory projection serves 32 queries per pass over the bank (pio_mem_project): two batches at a time
-            if len(g.pending) == self.project_batches or len(g.counts) == self.group_batches:
-                self._flush(g)
+            imgs = held[0][0] if len(held) == 1 else torch.cat([h[0] for h in held], dim=0)
+            want_qkv = self.use_attention_tracing and any(h[1] is not None for h in held)
+            tokens_all, qkv_all = eng.vit_forward(imgs, want_qkv=want_qkv)
+            s = 0
+            for im, traces in held:
+                n = im.shape[0]
+                tokens = tokens_all[s:s + n]
+                if traces is None:
+                    emb = tokens[:, 0].contiguous()
+                else:
+                    grids = eng.trace_grids(traces).view(n, -1)
+                    if self.use_attention_tracing:
+                        self_attn, _, _, _ = eng.cls_attention(qkv_all[s:s + n], tokens)
+                        grids = self_attn * grids
+                    emb = eng.region_reduce(tokens, grids, None, 1.0 / m.num_patch_tokens)
+                s += n
+                g.rows += n
+                g.counts.append(n)
+                g.pending.append((emb, stream, m))
+                if len(g.pending) == self.project_batches or len(g.counts) == self.group_batches:
+                    self._flush(g)
 
     def _flush(self, g: _Group) -> None:
         """Project (and invert) the pending region embeddings of the group together, into its prefix buffer."""
@@ -174,10 +186,17 @@ class TraceCaptionPipeline:
                 while pending:
                     for caps in self._collect(pending.popleft()):
                         yield caps
-            if g.rows + imgs.shape[0] > g.prefix.shape[0]:
+            held_rows = sum(h[0].shape[0] for h in self._held)
+            if g.rows + held_rows + imgs.shape[0] > g.prefix.shape[0]:
                 raise ValueError("batch of %d does not fit the %d-prefix decode group" % (imgs.shape[0], g.prefix.shape[0]))
-            self._stage(g, imgs, traces)
-            if len(g.counts) == self.group_batches or g.rows + imgs.shape[0] > g.prefix.shape[0]:
+            self._held.append((imgs, traces))
+            held_rows += imgs.shape[0]
+            full = (len(g.counts) + len(self._held) == self.group_batches or
+                    g.rows + held_rows + imgs.shape[0] > g.prefix.shape[0])
+            if len(self._held) == self.vit_batches or full:
+                self._stage(g, self._held)
+                self._held = []
+            if full:
                 self._decode(g)
                 pending.append(g)
                 cur ^= 1
@@ -185,6 +204,9 @@ class TraceCaptionPipeline:
                     for caps in self._collect(pending.popleft()):
                         yield caps
         g = self.groups[cur]
+        if self._held:
+            self._stage(g, self._held)
+            self._held = []
         if g.rows:
             self._decode(g)
             pending.append(g)

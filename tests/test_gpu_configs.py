@@ -156,6 +156,9 @@ def test_grouped_decode_pipeline_matches_synchronous_forward():
         want = [m(imgs, get_cls_capt=False, traces=tr, use_attention_tracing=attn)["trace_capts"] for imgs, tr in batches]
         got = list(TraceCaptionPipeline(m, group_batches=3, use_attention_tracing=attn).run(batches))
         assert got == want
+        # consecutive batches sharing one ViT launch (here cut again by max_batch = 8 inside the engine): same captions
+        got = list(TraceCaptionPipeline(m, group_batches=4, use_attention_tracing=attn, vit_batches=3).run(batches))
+        assert got == want
     want = [m(imgs, get_cls_capt=True)["cls_capt"] for imgs, _ in batches]
     got = list(TraceCaptionPipeline(m, group_batches=4).run((imgs, None) for imgs, _ in batches))
     assert got == want

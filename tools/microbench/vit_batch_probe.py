@@ -1,0 +1,27 @@
+"""ViT forward time per image as a function of the images per launch (diagnostic):  python tools/microbench/vit_batch_probe.py"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import bench
+from patchioner_amd import Patchioner, weights as W
+
+def main():
+    torch.cuda.set_device(0)
+    cfg = {"decap_weights": W.synth_decap(3), "dino_weights": W.synth_dinov2(1), "memory_bank": W.synth_bank(6, 4096).cuda(),
+           "prefix_size": 768, "linear_talk2dino": False, "support_memory_size": 4096, "dino_model": "dinov2_vitb14_reg",
+           "normalize": True, "resize_dim": bench.CROP, "crop_dim": bench.CROP, "max_batch": 128, "max_prefixes": 64}
+    m = Patchioner.from_config(cfg, device="cuda:0")
+    eng = m.engine
+    for B in (16, 32, 48, 64, 128):
+        imgs = W.synth_images(1, B, bench.CROP).cuda()
+        for _ in range(3): eng.vit_forward(imgs)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        R = 20
+        for _ in range(R): eng.vit_forward(imgs)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / R
+        print("B=%3d  %.3f ms per launch   %.1f us per image" % (B, dt * 1e3, dt * 1e6 / B), flush=True)
+
+main()
