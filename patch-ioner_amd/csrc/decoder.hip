@@ -477,11 +477,28 @@ typedef const __attribute__((address_space(1))) void* dec_gbl_ptr_t;
 // waves; W goes straight to registers (12 x 16 B per lane).  Both are inline asm with hand-counted vmcnt (see
 // k_lmhead_wide for why); chunk q is consumed while the later chunks are in flight.  Tile shapes are picked per GEMM
 // and prefix count from tools/microbench/dec_bench.hip (128 prefixes: 32 x 48 for qkv / fc, 32 x 16 for proj,
-// 64 x 32 x 4 k-slices for fc2: 12.6 / 6.3 / 12.9 / 15.4 us against 16.5 / 16.3 / 17.0 / 21.1).
+// 64 x 32 x 4 k-slices for fc2: 11.6 / 6.1 / 12.2 / 15.0 us against 16.5 / 16.3 / 17.0 / 21.1; 64 prefixes:
+// 8.3 / 4.8 / 8.8 / 11.1 against 9.9 / 9.6 / 10.1 / 13.3).
 // Measured and dropped: splitting K = 768 as well (bricks of 64 x 64 x 128..384 with the ticket) -- the ticket's
 // serial tail (store -> write-back -> cross-XCD atomic -> invalidate -> slab re-read) costs 5-14 us on this part,
 // as much as the smaller bricks save.
 //   grid = (Nout / (16 NCG), KS, ceil(N / (16 RGB))), 256 NCG threads.
+// vm queue of a k_dec_gemm_b wave and the vmcnt that retires everything chunk q needs at the wait of step q.
+//   order: W(0) X(0) W(1) X(1) .. W(RB-1) X(RB-1) W(RB) .. W(11) | X(RB) .. X(11), the late X(s+RB-1) issued in step
+//   s >= 1 after that step's wait; X(c) is `xops` LDS-DMA operations (0 for a wave that issues none).
+__host__ __device__ constexpr int dec_b_allowed(int q, int RB, int xops) {
+  int total = 0, need = 0;
+  for (int c = 0; c < RB; ++c) {
+    total += 1; if (c <= q) need = total;
+    total += xops; if (c <= q) need = total;
+  }
+  for (int c = RB; c < 12; ++c) { total += 1; if (c <= q) need = total; }
+  for (int st = 1; st < q; ++st) {
+    const int c = st + RB - 1;
+    if (c < 12) { total += xops; if (c <= q) need = total; }
+  }
+  return total - need;
+}
 template <int C> __device__ __forceinline__ void dec_wait_vm(f32x4& w) {
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w) : "n"(C) : "memory");
 }
@@ -492,12 +509,15 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_b(const float* __rest
   static_assert(!(LN && KS > 1), "LayerNorm row sums need the whole row in one workgroup");
   static_assert(RGB == 1 || RGB == 2 || RGB == 4, "row groups per workgroup");
   constexpr int NW = 4 * NCG, CH = 64, NQ = 12, ROWS = 16 * RGB, XB = ROWS * CH;
-  constexpr int RB = RGB == 4 ? 8 : 12;                     // ring depth (RB == NQ: every chunk has its own buffer)
+  constexpr int RB = RGB == 4 ? 8 : 12;                     // ring depth (RB == NQ: the whole K slice of X is resident)
+  constexpr bool RESIDENT = RB == NQ;
   constexpr int PIECES = 4 * RGB;                           // 1-KiB LDS-DMA pieces per chunk
-  constexpr int NISS = PIECES < NW ? PIECES : NW;           // waves that issue them
-  constexpr int DPW = PIECES / NISS;
-  static_assert(DPW * NISS == PIECES, "pieces must divide among the issuing waves");
-  extern __shared__ __attribute__((aligned(16))) float lsm[];      // ring [RB][ROWS][64]; afterwards partial tiles [NW][RGB][256]
+  // RESIDENT: the NQ * PIECES pieces of the slice are dealt round-robin to the waves (piece p = wid + NW i: chunk
+  // p / PIECES, rows 4 (p % PIECES) ..), so EVERY wave issues the same number of operations and one set of hand-
+  // counted waits serves all of them.  Ring: NW divides PIECES, wave w takes pieces w, w + NW, .. of every chunk.
+  constexpr int TP = RESIDENT ? NQ * PIECES / NW : PIECES / NW;
+  static_assert(TP * NW == (RESIDENT ? NQ * PIECES : PIECES), "pieces must divide among the waves");
+  extern __shared__ __attribute__((aligned(16))) float lsm[];      // [RB][ROWS][64]; afterwards partial tiles [NW][RGB][256]
   __shared__ float s_sum[LN ? 4 : 1][ROWS], s_sq[LN ? 4 : 1][ROWS];
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -508,55 +528,74 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_b(const float* __rest
   const int kbase = blockIdx.y * (NQ * CH);
   const int j = (blockIdx.x * NCG + cg) * 16 + li;
   const float* wp = W + (size_t)j * K + kbase + 16 * kw + 4 * kq;
-  static_assert(NISS == NW || (DPW == 1 && RB == NQ), "see the wait in PIO_BSTEP");
-  const bool issuer = NISS == NW || wid < NISS;             // wave-uniform
   f32x4 w[NQ];
+  // A piece covers rows 4t .. 4t+3 of a chunk (1 KiB); lane l fills slot (l & 15) of row 4t + (l >> 4) and therefore
+  // fetches source slot (l & 15) ^ (row & 15).
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(dec_lds_ptr_t)lsm;
+#define PIO_DMA(gptr, ldsaddr)                                                                                 \
+  do {                                                                                                         \
+    uint32_t _keep;                                                                                            \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(_keep) : "v"(gptr), "s"(ldsaddr) : "memory");                                         \
+  } while (0)
+#define PIO_WISSUE(q)                                                                                          \
+  do {                                                                                                         \
+    const float* _p = wp + (q) * CH;                                                                           \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[q]) : "v"(_p) : "memory");                         \
+  } while (0)
+  uint32_t xoff[RESIDENT ? 1 : TP];
+  if constexpr (RESIDENT) {
+    // vm queue: X pieces (L2-hot, TP per wave) | W(0) .. W(11) (the MALL / HBM stream).  Step 0 waits for this wave's
+    // pieces and W(0), the barrier makes that "all of X"; step q > 0 only waits for W(q): at most 11 - q outstanding.
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const float* _p = wp + q * CH;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[q]) : "v"(_p) : "memory");
-  }
-  // LDS-DMA pieces of a chunk: piece t = wid + NISS i covers rows 4t .. 4t+3 (1 KiB); lane l fills slot (l & 15) of
-  // row 4t + (l >> 4) and therefore fetches source slot (l & 15) ^ (row & 15).
-  uint32_t xoff[DPW];
+    for (int i = 0; i < TP; ++i) {
+      const int p = wid + NW * i, ch = p / PIECES, t = p % PIECES;
+      const int row = 4 * t + (lane >> 4);
+      const int rc = row0 + row < N ? row0 + row : N - 1;
+      const float* g = X + (size_t)rc * K + kbase + ch * CH + 4 * ((lane & 15) ^ (row & 15));
+      const uint32_t l = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)((ch * XB + t * 256) * 4));
+      PIO_DMA(g, l);
+    }
 #pragma unroll
-  for (int i = 0; i < DPW; ++i) {
-    const int row = (4 * (wid + NISS * i) + (lane >> 4)) & (ROWS - 1);
-    const int rc = row0 + row < N ? row0 + row : N - 1;
-    xoff[i] = (uint32_t)rc * K + kbase + 4 * ((lane & 15) ^ (row & 15));
+    for (int q = 0; q < NQ; ++q) PIO_WISSUE(q);
+  } else {
+    // vm queue: W(0) X(0) W(1) X(1) .. W(RB-1) X(RB-1) W(RB) .. W(11) | X(RB) .. X(11), the late X(s+RB-1) issued in
+    // step s >= 1; the waits are counted by dec_b_allowed.
+#pragma unroll
+    for (int i = 0; i < TP; ++i) {
+      const int row = 4 * (wid + NW * i) + (lane >> 4);
+      const int rc = row0 + row < N ? row0 + row : N - 1;
+      xoff[i] = (uint32_t)rc * K + kbase + 4 * ((lane & 15) ^ (row & 15));
+    }
   }
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(dec_lds_ptr_t)lsm + (uint32_t)wid * 1024u;
 #define PIO_XISSUE(q)                                                                                          \
   do {                                                                                                         \
-    if (issuer) {                                                                                              \
-      _Pragma("unroll") for (int i = 0; i < DPW; ++i) {                                                        \
-        const float* _g = X + (q) * CH + xoff[i];                                                              \
-        const uint32_t _l = lds0 + (uint32_t)((((q) % RB) * XB + i * NISS * 256) * 4);                         \
-        uint32_t _keep;                                                                                        \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(_keep) : "v"(_g), "s"(_l) : "memory");                                            \
-      }                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < TP; ++i) {                                                           \
+      const float* _g = X + (q) * CH + xoff[i];                                                                \
+      const uint32_t _l = lds_base + (uint32_t)((((q) % RB) * XB + (wid + NW * i) * 256) * 4);                 \
+      PIO_DMA(_g, _l);                                                                                         \
     }                                                                                                          \
   } while (0)
+  if constexpr (!RESIDENT) {
 #pragma unroll
-  for (int q = 0; q < RB; ++q) PIO_XISSUE(q);
+    for (int q = 0; q < RB; ++q) { PIO_WISSUE(q); PIO_XISSUE(q); }
+#pragma unroll
+    for (int q = RB; q < NQ; ++q) PIO_WISSUE(q);
+  }
   f32x4 acc[RGB];
   float sx[RGB], sq[RGB];
 #pragma unroll
   for (int g = 0; g < RGB; ++g) { acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; sx[g] = 0.f; sq[g] = 0.f; }
-  // vm queue of an issuing wave: W(0..11) | X(0) .. X(RB-1) | X(RB) .. X(11) (X(q+RB-1) is issued in step q >= 1).
-  // At the wait of step q the youngest chunk issued is min(11, RB - 1 + max(q - 1, 0)); everything up to chunk q has
-  // landed once at most DPW * (that - q) operations are outstanding.  A wave that issues no pieces (NISS < NW: then
-  // DPW == 1 and RB == NQ) has only its weight loads in the queue and needs W(q): at most 11 - q outstanding -- the
-  // same immediate, so the wait is branch-free (hipcc, given two asm waits on one register set in the two arms of a
-  // branch, hoists a copy of the registers above them: caught by tools/microbench/asm_load_audit.py).
 #define PIO_BSTEP(q)                                                                                           \
   do {                                                                                                         \
-    constexpr int _y0 = RB - 1 + ((q) > 1 ? (q) - 1 : 0);                                                      \
-    constexpr int _young = _y0 < NQ - 1 ? _y0 : NQ - 1;                                                        \
-    dec_wait_vm<DPW * (_young - (q))>(w[q]);                                                                   \
-    __builtin_amdgcn_s_barrier();      /* chunk q landed in every wave; every wave is done with chunk q-1 */    \
-    if ((q) >= 1 && (q) + RB - 1 < NQ) PIO_XISSUE((q) + RB - 1);                                               \
+    if constexpr (RESIDENT) {                                                                                  \
+      dec_wait_vm<NQ - 1 - (q)>(w[q]);                                                                         \
+      if ((q) == 0) __builtin_amdgcn_s_barrier();      /* every wave's pieces have landed: all of X */          \
+    } else {                                                                                                   \
+      dec_wait_vm<dec_b_allowed(q, RB, TP)>(w[q]);                                                             \
+      __builtin_amdgcn_s_barrier();    /* chunk q landed in every wave; every wave is done with chunk q-1 */    \
+      if ((q) >= 1 && (q) + RB - 1 < NQ) PIO_XISSUE((q) + RB - 1);                                             \
+    }                                                                                                          \
     const float* _xb = lsm + ((q) % RB) * XB;                                                                  \
     _Pragma("unroll") for (int g = 0; g < RGB; ++g) {                                                          \
       const float4 xf = *(const float4*)(_xb + (16 * g + li) * CH + (((4 * kw + kq) ^ li) << 2));              \
@@ -564,7 +603,7 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_b(const float* __rest
       acc[g] = mfma16f(xf.y, w[q][1], acc[g]);                                                                 \
       acc[g] = mfma16f(xf.z, w[q][2], acc[g]);                                                                 \
       acc[g] = mfma16f(xf.w, w[q][3], acc[g]);                                                                 \
-      if (LN && cg == 0) {                                                                                     \
+      if (LN) {          /* every wave keeps the row sums (a few VALU ops, no branch); cg == 0 publishes them */ \
         sx[g] += (xf.x + xf.y) + (xf.z + xf.w);                                                                \
         sq[g] += (xf.x * xf.x + xf.y * xf.y) + (xf.z * xf.z + xf.w * xf.w);                                    \
       }                                                                                                        \
@@ -574,6 +613,8 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_b(const float* __rest
   PIO_BSTEP(6); PIO_BSTEP(7); PIO_BSTEP(8); PIO_BSTEP(9); PIO_BSTEP(10); PIO_BSTEP(11);
 #undef PIO_BSTEP
 #undef PIO_XISSUE
+#undef PIO_WISSUE
+#undef PIO_DMA
   const float bj = bias[j];
   const float cj = LN ? cvec[j] : 0.f;
   if (LN && cg == 0) {
@@ -679,7 +720,7 @@ static hipError_t dec_gemm(const float* W, const float* X, int N, int Nout, int 
       const bool wide = Nout >= 2304;       // qkv / fc: 48 (32) columns per workgroup; proj: 16
       if (rg > 4) return wide ? dec_gemm_b_launch<2, 3, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s)
                               : dec_gemm_b_launch<2, 1, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
-      if (rg > 2) return wide ? dec_gemm_b_launch<1, 3, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s)
+      if (rg > 2) return wide ? dec_gemm_b_launch<2, 2, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s)
                               : dec_gemm_b_launch<1, 1, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
       return wide ? dec_gemm_b_launch<1, 2, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s)
                   : dec_gemm_b_launch<1, 1, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);

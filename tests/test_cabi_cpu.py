@@ -112,6 +112,9 @@ def test_inline_asm_weight_loads_are_not_touched_before_their_wait(tmp_path):
         one = tmp_path / (name + ".s")
         one.write_text(body)
         assert "scratch_" not in body, name + ": spills next to asm loads"
+        if "k_dec_gemm_b" in name:   # the audit reads the listing as straight-line code: true only without branches
+            region = body[body.index("global_load_dwordx4"):body.rindex("v_mfma")]
+            assert "s_cbranch" not in region, name + ": branch inside the hand-counted region"
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "microbench", "asm_load_audit.py"), str(one)],
                              check=True, capture_output=True, text=True).stdout
         assert out.startswith("0 violations"), name + ": " + out[:400]
