@@ -13,7 +13,7 @@ def main():
            "normalize": True, "resize_dim": bench.CROP, "crop_dim": bench.CROP, "max_batch": 128, "max_prefixes": 64}
     m = Patchioner.from_config(cfg, device="cuda:0")
     eng = m.engine
-    for B in (16, 32, 48, 64, 128):
+    for B in ([int(a) for a in sys.argv[1:]] or (16, 32, 48, 64, 128)):
         imgs = W.synth_images(1, B, bench.CROP).cuda()
         for _ in range(3): eng.vit_forward(imgs)
         torch.cuda.synchronize()
