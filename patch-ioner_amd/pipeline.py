@@ -45,12 +45,16 @@ class TraceCaptionPipeline:
 
     def __init__(self, model, group_batches: int = 4, use_attention_tracing: bool = False, steps: int = 30,
                  stage_replicas: Sequence = (), stage_cus: Optional[int] = None, decode_cus: Optional[int] = None,
-                 vit_batches: int = 1):
+                 vit_batches: int = 1, decode_replicas: Sequence = ()):
         """``stage_replicas``: further Patchioner instances holding the SAME weights (each has its own ViT
         workspace); stage 1 of consecutive batches then alternates over the replicas, each on its own stream,
         so that one batch's GEMM tails, epilogues and launch gaps are filled by the other's kernels."""
         self.m, self.eng = model, model.engine
         self.stage_models = [model] + list(stage_replicas)
+        # ``decode_replicas``: further instances (same weights, own decoder workspace) so that consecutive groups'
+        # decodes run concurrently, each on its own stream: a decode is a chain of ~660 small dependent kernels that
+        # stretches 2x when it shares the chip with stage 1, and two chains in flight hide each other's waits.
+        self.decode_engines = [model.engine] + [r.engine for r in decode_replicas]
         self.group_batches = group_batches
         self.vit_batches = max(1, int(vit_batches))
         self._held: List = []             # batches waiting for their shared ViT launch
@@ -65,10 +69,12 @@ class TraceCaptionPipeline:
         self._raw_streams = []
         self.stage_streams = [self._make_stream(stage_cus) for _ in self.stage_models]
         # ... and the decode to the LAST `decode_cus` compute units (a true partition when stage_cus + decode_cus <= total)
-        self.sb = self._make_stream(decode_cus, from_top=True)
+        self.decode_streams = [self._make_stream(decode_cus, from_top=True) for _ in self.decode_engines]
+        self.sb = self.decode_streams[0]
+        self._ndecoded = 0
         self._nstaged = 0
         cap = self.eng.max_prefixes
-        self.groups = [_Group(cap, self.eng.prefix_size, steps, self.eng.device) for _ in range(2)]
+        self.groups = [_Group(cap, self.eng.prefix_size, steps, self.eng.device) for _ in range(1 + len(self.decode_engines))]
         self.last_ids: Optional[torch.Tensor] = None
 
     def _make_stream(self, n_cus, from_top: bool = False):
@@ -92,7 +98,8 @@ class TraceCaptionPipeline:
             g.staged = []
             g.decoded = torch.cuda.Event()
         self.stage_streams = [torch.cuda.Stream() for _ in self.stage_models]
-        self.sb = torch.cuda.Stream()
+        self.decode_streams = [torch.cuda.Stream() for _ in self.decode_engines]
+        self.sb = self.decode_streams[0]
         import gc
         gc.collect()
         for raw in self._raw_streams:
@@ -156,14 +163,17 @@ class TraceCaptionPipeline:
     # ---- stage 2: one decode for the group, on stream B ---------------------------------------------------
     def _decode(self, g: _Group) -> None:
         self._flush(g)
-        with torch.cuda.stream(self.sb):
+        k = self._ndecoded % len(self.decode_engines)
+        self._ndecoded += 1
+        eng, sb = self.decode_engines[k], self.decode_streams[k]
+        with torch.cuda.stream(sb):
             for ev in g.staged:
-                self.sb.wait_event(ev)
+                sb.wait_event(ev)
             g.staged = []
-            ids, _ = self.eng.decode_greedy(g.prefix[:g.rows], steps=self.steps)
+            ids, _ = eng.decode_greedy(g.prefix[:g.rows], steps=self.steps)
             g.ids_dev = ids
             g.ids_host[:g.rows].copy_(ids, non_blocking=True)
-            g.decoded.record(self.sb)
+            g.decoded.record(sb)
         g.busy = True
 
     def _collect(self, g: _Group) -> List[List[str]]:
@@ -199,8 +209,8 @@ class TraceCaptionPipeline:
             if full:
                 self._decode(g)
                 pending.append(g)
-                cur ^= 1
-                if self.groups[cur].busy:          # keep at most one decode in flight behind the staging
+                cur = (cur + 1) % len(self.groups)
+                if self.groups[cur].busy:          # its buffer is needed now: at most len(groups) - 1 decodes in flight
                     for caps in self._collect(pending.popleft()):
                         yield caps
         g = self.groups[cur]

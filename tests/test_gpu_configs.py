@@ -162,6 +162,11 @@ def test_grouped_decode_pipeline_matches_synchronous_forward():
     want = [m(imgs, get_cls_capt=True)["cls_capt"] for imgs, _ in batches]
     got = list(TraceCaptionPipeline(m, group_batches=4).run((imgs, None) for imgs, _ in batches))
     assert got == want
+    # consecutive groups decoded concurrently on replicas (own decoder workspace and stream each): same captions, in order
+    reps = [_model(224, True, max_batch=8) for _ in range(2)]
+    got = list(TraceCaptionPipeline(m, group_batches=2, vit_batches=2, decode_replicas=reps).run((imgs, None) for imgs, _ in batches))
+    assert got == want
+    del reps
     # CU-masked streams (pio_stream_create): same captions; close() releases them and the pipeline stays usable
     pipe = TraceCaptionPipeline(m, group_batches=4, stage_cus=192, decode_cus=64)
     assert list(pipe.run((imgs, None) for imgs, _ in batches)) == want
