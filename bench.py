@@ -98,7 +98,7 @@ def main():
                     help="mode=group: model replicas (own ViT workspace, own stream) that stage 1 alternates over")
     ap.add_argument("--decode-streams", type=int, default=int(os.environ.get("PIO_BENCH_DECODE_STREAMS", "3")),
                     help="mode=group: model replicas (own decoder workspace, own stream) that consecutive groups' decodes alternate over")
-    ap.add_argument("--vit-batches", type=int, default=int(os.environ.get("PIO_BENCH_VIT_BATCHES", "2")),
+    ap.add_argument("--vit-batches", type=int, default=int(os.environ.get("PIO_BENCH_VIT_BATCHES", "4")),
                     help="mode=group: consecutive bs-16 batches that share one ViT launch (1 = a launch per batch)")
     args = ap.parse_args()
 
