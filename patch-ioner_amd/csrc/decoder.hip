@@ -47,6 +47,12 @@ namespace pio {
 #ifndef PIO_LMF16_NT          // which row-group counts of k_lmhead_f16 stream their weights non-temporally
 #define PIO_LMF16_NT(RG) ((RG) >= 4)
 #endif
+#ifndef PIO_LMF16_DEEP        // 64 / 128 prefixes: three X~ / weight chunks in flight instead of one / two (measured: 56.6 vs 50.3 us, off)
+#define PIO_LMF16_DEEP 0
+#endif
+#ifndef PIO_LMF16_ABL         // timing ablations of k_lmhead_f16 (diagnostic builds only): 1 no epilogue, 2 no X~ DMA, 3 no MFMA
+#define PIO_LMF16_ABL 0
+#endif
 #ifndef PIO_LMF16_FUSED       // <= 16 prefixes: statistics / fp16 conversion inside the head kernel
 #define PIO_LMF16_FUSED 1
 #endif
@@ -83,6 +89,19 @@ __device__ __forceinline__ bool arg_better(float v, int i, float best, int bi) {
   if (vn != bn) return vn;
   if (vn) return i < bi;
   return v > best || (v == best && i < bi);
+}
+
+// max over the 16 lanes of a DPP row (lanes 16r .. 16r+15), result in every lane: four v_max_f32_dpp instead of four
+// ds_bpermute round trips (__shfl_xor), which serialised the fp16 head's epilogue (32 such reductions per lane).
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f32<0xB1>(v));     // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_f32<0x4E>(v));     // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_f32<0x141>(v));    // row_half_mirror: lane i <-> 7 - i
+  v = fmaxf(v, dpp_f32<0x140>(v));    // row_mirror:      lane i <-> 15 - i
+  return v;
 }
 
 __device__ __forceinline__ float gelu_new(float x) {
@@ -999,7 +1018,7 @@ __global__ __launch_bounds__(256, 2) void k_lmhead_f16(const uint16_t* __restric
 #define PIO_XISSUE(q, buf)                                                                                     \
   do {                                                                                                         \
     _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                          \
-      if (wid + 4 * i < NP) {                                                                                  \
+      if (PIO_LMF16_ABL != 2 && (NP % 4 == 0 || wid + 4 * i < NP)) {                                           \
         const char* _g = (const char*)Xh + (q) * (CH * 2) + xoff[i];                                           \
         const uint32_t _l = lds0 + (uint32_t)((buf) * XB + i * 4096);                                          \
         uint32_t _keep;                                                                                        \
@@ -1018,52 +1037,90 @@ __global__ __launch_bounds__(256, 2) void k_lmhead_f16(const uint16_t* __restric
     }                                                                                                          \
   } while (0)
 #define PIO_WWAIT(set, cnt) asm volatile("s_waitcnt vmcnt(" #cnt ")" : "+v"(w[set][0]), "+v"(w[set][1]) :: "memory")
-  constexpr int XI = (NP + 3 - 0) / 4 > 0 ? 1 : 1;   // every wave issues the same number of X pieces per chunk when NP % 4 == 0
-  f32x4 w[3][2];
+  // RG >= 4 (64 / 128 prefixes): the X~ chunk is 8 / 16 KB and a chunk's MFMAs last ~0.1 us, far less than an L2 round
+  // trip, so one chunk of lookahead left the workgroup waiting on every chunk (50 us for 77 MB at 128 prefixes): ring of
+  // DEPTH + 1 buffers and weight sets, DEPTH chunks in flight.  Every wave issues PPW pieces per chunk there (NP % 4 == 0).
+  constexpr bool DEEP = PIO_LMF16_DEEP != 0 && RG >= 4;
+  constexpr int DEPTH = DEEP ? 3 : 1, NSET = DEEP ? DEPTH + 1 : 3;
+  static_assert(!DEEP || NP % 4 == 0, "uniform vm queue");
+  f32x4 w[NSET][2];
   f32x4 acc[RG];
 #pragma unroll
   for (int g = 0; g < RG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  PIO_WLOAD(0, 0);
-  PIO_XISSUE(0, 0);
-  PIO_WLOAD(1, 1);
+#define PIO_COMPUTE(q, set, buf)                                                                               \
+  do {                                                                                                         \
+    const char* xb = lsh + (buf) * XB;                                                                         \
+    _Pragma("unroll") for (int g = 0; g < RG; ++g) {                                                           \
+      _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                          \
+        const int row = 16 * g + li;                                                                           \
+        const dec_h8 xf = *(const dec_h8*)(xb + row * 128 + (((4 * c + kq) ^ ((row >> 1) & 7)) << 4));         \
+        if (PIO_LMF16_ABL == 3) acc[g][0] += (float)xf[0] * w[set][c][0];                                      \
+        else acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, __builtin_bit_cast(dec_h8, w[set][c]), acc[g], 0, 0, 0); \
+      }                                                                                                        \
+    }                                                                                                          \
+  } while (0)
+  if constexpr (DEEP) {
+    // queue: W(0) X(0) .. W(DEPTH-1) X(DEPTH-1) | step q: [wait chunk q] [barrier] W(q+DEPTH) X(q+DEPTH) [compute q].
+    // At the wait of step q chunks q+1 .. min(q+DEPTH-1, 11) are behind chunk q: (2 + PPW) operations each.
+#define PIO_DSTEP(q)                                                                                           \
+    do {                                                                                                       \
+      constexpr int _last = (q) + DEPTH - 1 < NCH - 1 ? (q) + DEPTH - 1 : NCH - 1;                             \
+      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[(q) % NSET][0]), "+v"(w[(q) % NSET][1]) : "n"((_last - (q)) * (2 + PPW)) : "memory"); \
+      __builtin_amdgcn_s_barrier();    /* chunk q landed in every wave; every wave is done with chunk q-1 */    \
+      if ((q) + DEPTH < NCH) { PIO_WLOAD(((q) + DEPTH) % NSET, (q) + DEPTH); PIO_XISSUE((q) + DEPTH, ((q) + DEPTH) % NSET); } \
+      PIO_COMPUTE(q, (q) % NSET, (q) % NSET);                                                                  \
+    } while (0)
 #pragma unroll
-  for (int q = 0; q < NCH; ++q) {
-    const int r = q % 3;
-    // queue per chunk: W(q) | X(q) | W(q+1): W(q), X(q) have landed once only the 2 loads of W(q+1) are outstanding
-    if (q + 1 < NCH) PIO_WWAIT(r, 2);
-    else PIO_WWAIT(r, 0);
-    __builtin_amdgcn_s_barrier();
-    if (q + 1 < NCH) PIO_XISSUE(q + 1, (q + 1) & 1);
-    if (q + 2 < NCH) PIO_WLOAD((r + 2) % 3, q + 2);
-    const char* xb = lsh + (q & 1) * XB;
+    for (int q = 0; q < DEPTH; ++q) { PIO_WLOAD(q, q); PIO_XISSUE(q, q); }
+    PIO_DSTEP(0); PIO_DSTEP(1); PIO_DSTEP(2); PIO_DSTEP(3); PIO_DSTEP(4); PIO_DSTEP(5);
+    PIO_DSTEP(6); PIO_DSTEP(7); PIO_DSTEP(8); PIO_DSTEP(9); PIO_DSTEP(10); PIO_DSTEP(11);
+#undef PIO_DSTEP
+  } else {
+    PIO_WLOAD(0, 0);
+    PIO_XISSUE(0, 0);
+    PIO_WLOAD(1, 1);
 #pragma unroll
-    for (int g = 0; g < RG; ++g) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int row = 16 * g + li;
-        const dec_h8 xf = *(const dec_h8*)(xb + row * 128 + (((4 * c + kq) ^ ((row >> 1) & 7)) << 4));
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, __builtin_bit_cast(dec_h8, w[r][c]), acc[g], 0, 0, 0);
-      }
+    for (int q = 0; q < NCH; ++q) {
+      const int r = q % 3;
+      // queue per chunk: W(q) | X(q) | W(q+1): W(q), X(q) have landed once only the 2 loads of W(q+1) are outstanding
+      if (q + 1 < NCH) PIO_WWAIT(r, 2);
+      else PIO_WWAIT(r, 0);
+      __builtin_amdgcn_s_barrier();
+      if (q + 1 < NCH) PIO_XISSUE(q + 1, (q + 1) & 1);
+      if (q + 2 < NCH) PIO_WLOAD((r + 2) % 3, q + 2);
+      PIO_COMPUTE(q, r, q & 1);
     }
   }
+#undef PIO_COMPUTE
 #undef PIO_XISSUE
 #undef PIO_WLOAD
 #undef PIO_WWAIT
-  (void)XI;
+  // the rows' statistics through LDS (one round trip instead of 4 RG loads per lane).  The epilogue was 17 of this
+  // kernel's 50 us at 128 prefixes, most of it the four ds_bpermute round trips per group maximum: row16_max (DPP) -> 46 us.
+  // (Keeping only the group maxima, no approximate logits: 40.6 us, but k_dec_select_filter then evaluates all 16
+  //  columns of a candidate group exactly, 12.1 instead of 5.8 us: no net gain, dropped.)
+  __syncthreads();                                  // every wave is done with the X~ ring
+  float4* s_st = (float4*)lsh;
+  if (tid < ROWS) s_st[tid] = *(const float4*)(stats + 4 * (tid < N ? tid : N - 1));
+  __syncthreads();
   if (blk * 16 >= V) return;                        // wave-uniform: no columns
   const float cj = cvec[jc], dj = dvec[jc];
+  if (PIO_LMF16_ABL == 1) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < RG; ++g) t += acc[g][0] + acc[g][1] + acc[g][2] + acc[g][3];
+    if (t == 12345.678f) out[j] = t;
+    return;
+  }
 #pragma unroll
   for (int g = 0; g < RG; ++g)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int n = 16 * g + 4 * kq + i;
-      const int nc = n < N ? n : N - 1;
-      const float4 st = *(const float4*)(stats + 4 * nc);
+      const float4 st = s_st[n];
       const float v = j < V ? st.y * (acc[g][i] * (st.z * w_unscale) - st.x * cj) + dj : -INFINITY;
       if (n < N && j < V) out[(size_t)n * Vp + j] = v;
-      float gm = v;                                 // max over the wave's 16 columns (lanes li = 0..15 of this kq group)
-      gm = fmaxf(gm, __shfl_xor(gm, 1)); gm = fmaxf(gm, __shfl_xor(gm, 2));
-      gm = fmaxf(gm, __shfl_xor(gm, 4)); gm = fmaxf(gm, __shfl_xor(gm, 8));
+      const float gm = row16_max(v);                // max over the wave's 16 columns (lanes li = 0..15 of this kq group)
       if (li == 0 && n < N) gmax[(size_t)n * NGp + blk] = gm;
     }
 }
@@ -1170,9 +1227,7 @@ __global__ __launch_bounds__(256, 2) void k_lmhead_f16_fused(const uint16_t* __r
     const float4 st = *(const float4*)s_st[n];
     const float v = j < V ? st.y * (acc[i] * (st.z * w_unscale) - st.x * cj) + dj : -INFINITY;
     if (n < N && j < V) out[(size_t)n * Vp + j] = v;
-    float gm = v;
-    gm = fmaxf(gm, __shfl_xor(gm, 1)); gm = fmaxf(gm, __shfl_xor(gm, 2));
-    gm = fmaxf(gm, __shfl_xor(gm, 4)); gm = fmaxf(gm, __shfl_xor(gm, 8));
+    const float gm = row16_max(v);
     if (li == 0 && n < N) gmax[(size_t)n * NGp + blk] = gm;
   }
 }
@@ -1264,10 +1319,17 @@ __global__ __launch_bounds__(256) void k_dec_select_filter(const float* __restri
 template <int RG>
 static hipError_t launch_lmhead_f16(const DecoderArgs& a, hipStream_t s) {
   const int Vp = round_up(a.vocab, 64);
-  const int smem = 2 * RG * 16 * 64 * 2;
+  const int smem = (PIO_LMF16_DEEP != 0 && RG >= 4 ? 4 : 2) * RG * 16 * 64 * 2;
   const int NGp = round_up(ceil_div(a.vocab, 16), 64);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_lmhead_f16<RG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
   hipLaunchKernelGGL((k_lmhead_f16<RG>), dim3(ceil_div(a.vocab, 64)), dim3(256), smem, s, a.head_w16, (const _Float16*)a.xh, a.N,
-                     a.vocab, Vp, a.lm_stats, a.head_d, a.head_c, a.head_w16_unscale, a.logits, a.lm_gmax, NGp);
+                     a.vocab, Vp, a.lm_stats, a.head_d, a.head_c, a.head_w16_unscale, a.logits,
+                     a.lm_gmax, NGp);
   return hipGetLastError();
 }
 
