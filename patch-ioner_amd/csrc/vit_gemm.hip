@@ -63,7 +63,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 template <typename T, int EPI, int BM, int NBUF>
-__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void k_vit_gemm(const GemmArgs g) {
+__global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? 4 : 2)) void k_vit_gemm(const GemmArgs g) {
   constexpr int MI = BM / 64;                      // 32-row MFMA tiles per wave along M (waves are 2 x 2)
   constexpr int NPA = BM / 32;                     // 1-KiB A pieces per wave per K-tile (W: always 4)
   constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
@@ -305,6 +305,15 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void k_vit_gemm(const GemmA
 #ifndef PIO_GEMM_NBUF_WIDE
 #define PIO_GEMM_NBUF_WIDE 1
 #endif
+#ifndef PIO_GEMM_BM_BIG         // tile height of the wide GEMMs from PIO_GEMM_BIG_M rows on (0: never)
+#define PIO_GEMM_BM_BIG 0
+#endif
+#ifndef PIO_GEMM_NBUF_BIG
+#define PIO_GEMM_NBUF_BIG 1
+#endif
+#ifndef PIO_GEMM_BIG_M
+#define PIO_GEMM_BIG_M 8192
+#endif
 #ifndef PIO_GEMM_NBUF_NARROW
 #define PIO_GEMM_NBUF_NARROW 2
 #endif
@@ -329,14 +338,18 @@ template <typename T>
 static hipError_t launch_typed(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   switch (epi) {
     case EPI_PATCH_EMBED: return launch_one<T, EPI_PATCH_EMBED, PIO_GEMM_BM_NARROW, PIO_GEMM_NBUF_NARROW>(a, s);
-    case EPI_QKV: return launch_one<T, EPI_QKV, 128, PIO_GEMM_NBUF_WIDE>(a, s);
+    case EPI_QKV:
+      if constexpr (PIO_GEMM_BM_BIG != 0) { if (a.M >= PIO_GEMM_BIG_M) return launch_one<T, EPI_QKV, PIO_GEMM_BM_BIG == 0 ? 128 : PIO_GEMM_BM_BIG, PIO_GEMM_NBUF_BIG>(a, s); }
+      return launch_one<T, EPI_QKV, 128, PIO_GEMM_NBUF_WIDE>(a, s);
     case EPI_RESIDUAL:
       // 32 images and more per launch (the pipeline's shared ViT launches): 128-row tiles fill the chip on their own
       // (>= 1.5 workgroups per CU) and halve the W re-reads: 2.90 vs 3.21 ms per 32-image forward.  Same k order per
       // element, so the result does not depend on the tile height.
       if (ceil_div(a.M, 128) * (a.N / BN) >= 384) return launch_one<T, EPI_RESIDUAL, 128, 2>(a, s);
       return launch_one<T, EPI_RESIDUAL, PIO_GEMM_BM_NARROW, PIO_GEMM_NBUF_NARROW>(a, s);
-    case EPI_GELU: return launch_one<T, EPI_GELU, 128, PIO_GEMM_NBUF_WIDE>(a, s);
+    case EPI_GELU:
+      if constexpr (PIO_GEMM_BM_BIG != 0) { if (a.M >= PIO_GEMM_BIG_M) return launch_one<T, EPI_GELU, PIO_GEMM_BM_BIG == 0 ? 128 : PIO_GEMM_BM_BIG, PIO_GEMM_NBUF_BIG>(a, s); }
+      return launch_one<T, EPI_GELU, 128, PIO_GEMM_NBUF_WIDE>(a, s);
   }
   return hipErrorInvalidValue;
 }

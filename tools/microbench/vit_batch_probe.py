@@ -13,6 +13,10 @@ def main():
            "normalize": True, "resize_dim": bench.CROP, "crop_dim": bench.CROP, "max_batch": 128, "max_prefixes": 64}
     m = Patchioner.from_config(cfg, device="cuda:0")
     eng = m.engine
+    big = W.synth_images(7, 64, bench.CROP).cuda()
+    t64 = eng.vit_forward(big)[0]
+    t16 = torch.cat([eng.vit_forward(big[i:i + 16])[0] for i in range(0, 64, 16)])
+    print("64 images in one launch == 4 launches of 16, bitwise:", bool(torch.equal(t64, t16)), flush=True)
     for B in ([int(a) for a in sys.argv[1:]] or (16, 32, 48, 64, 128)):
         imgs = W.synth_images(1, B, bench.CROP).cuda()
         for _ in range(3): eng.vit_forward(imgs)
