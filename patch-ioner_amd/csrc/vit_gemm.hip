@@ -36,6 +36,9 @@ static constexpr int BN = 128, BK = 64;
 #ifndef PIO_ABL_NOSTORE       // epilogue without its global stores (LDS staging and arithmetic kept)
 #define PIO_ABL_NOSTORE 0
 #endif
+#ifndef PIO_GEMM_WIDE_OCC       // workgroups per CU the single-buffer (wide) form is compiled for
+#define PIO_GEMM_WIDE_OCC 4
+#endif
 #ifndef PIO_GEMM_BM_NARROW      // tile height used when N == D (proj, fc2, patch embed)
 #define PIO_GEMM_BM_NARROW 64
 #endif
@@ -63,7 +66,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 template <typename T, int EPI, int BM, int NBUF>
-__global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? 4 : 2)) void k_vit_gemm(const GemmArgs g) {
+__global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? PIO_GEMM_WIDE_OCC : 2)) void k_vit_gemm(const GemmArgs g) {
   constexpr int MI = BM / 64;                      // 32-row MFMA tiles per wave along M (waves are 2 x 2)
   constexpr int NPA = BM / 32;                     // 1-KiB A pieces per wave per K-tile (W: always 4)
   constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
