@@ -2,20 +2,22 @@
 
 The reference's call pattern is one synchronous ``model(batch)`` at a time.  On an MI355X that leaves the
 GPU mostly idle during the 30-step greedy decode: a decode step is a chain of ~22 small dependent kernels
-whose cost barely depends on the number of prefixes (16 prefixes: 5.8 ms, 64 prefixes: ~11 ms per 30 steps),
-and independent decode graphs on different streams overlap poorly (the command processor dispatches ~1 kernel
-per microsecond overall).  So this driver
+whose cost barely depends on the number of prefixes (16 prefixes: 4.5 ms, 128 prefixes: 8 ms per 30 steps),
+and whole forwards on independent streams overlap poorly (4 forwards on 4 streams: 3.0 k captions/s against 6.5 k
+here).  So this driver
 
   stage 1 (stream A): per batch  ViT -> CLS read-out -> trace grids -> weighted mean -> memory projection,
                       prefixes appended to a group buffer;
-  stage 2 (stream B): ONE greedy decode for the whole group (up to 64 prefixes = 4 batches of 16),
+  stage 2 (stream B): ONE greedy decode for the whole group (up to ``max_prefixes``: 128 = 8 batches of 16),
 
 and stage 2 of group g runs while stage 1 of group g+1 is being computed (small decode kernels fill the CUs
 the big ViT GEMMs leave).  ``vit_batches`` consecutive batches may also share one ViT launch (the backbone costs
 118 us per image at 16 images per launch, 86 us at 48 and more: fewer GEMM tails and launch gaps; the model's
 ``max_batch`` must cover them).  The token ids are bit-identical to the synchronous path either way (every ViT
 output element is computed in the same order whatever the launch holds; the decoder is exact fp32 and
-row-independent); captions come back per batch, in order.
+row-independent); captions come back per batch, in order.  ``decode_replicas`` lets consecutive groups decode
+concurrently (each on its own engine replica and stream): next to stage 1 a decode stretches about 2x, and with three
+in flight stage 1 never waits for a group buffer.
 """
 from __future__ import annotations
 
