@@ -86,8 +86,9 @@ def cpu_baseline():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=128,
+                    help="timed steps (16 groups of 8 batches by default: the pipeline's fill and drain, about 5 ms, are inside the timed region)")
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("PIO_BENCH_IN_FLIGHT", "8")),
                     help="batches per decode group (mode=group: stage 1 runs per bs-16 batch, ONE greedy decode serves "
