@@ -291,13 +291,16 @@ def test_ctx_cleaner_kernel_and_forward(O, golden):
 
 
 def test_pipeline_soak_is_deterministic():
-    """300 batches of the same input through the grouped-decode pipeline (staging rings, two streams, graph replays,
-    hand-counted asynchronous loads in the LM head): every group's token ids equal the first group's."""
+    """300 batches of the same input through the grouped-decode pipeline (staging rings, shared ViT launches, decodes of
+    consecutive groups in flight on three engines, graph replays, hand-counted asynchronous loads in the decoder GEMMs
+    and the LM head): every group's token ids equal the first group's."""
     from patchioner_amd.pipeline import TraceCaptionPipeline
-    m = _model(224, True, max_batch=16)
+    m = _model(224, True, max_batch=32)
     imgs = W.synth_images(55, 16, 224).cuda()
     traces = [gc.block_trace(i % 13, (3 * i) % 13) for i in range(16)]
-    pipe = TraceCaptionPipeline(m, group_batches=4)
+    # the bench's shape: shared ViT launches, paired projections, three decodes in flight on engine replicas
+    reps = [_model(224, True, max_batch=32) for _ in range(2)]
+    pipe = TraceCaptionPipeline(m, group_batches=4, vit_batches=2, decode_replicas=reps)
     first, seen, groups = None, None, 0
     for _ in pipe.run((imgs, traces) for _ in range(300)):
         if pipe.last_ids is not seen:
