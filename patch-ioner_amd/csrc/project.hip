@@ -26,6 +26,9 @@ namespace pio {
 #ifndef PIO_PROJECT_Q32       // 32 queries per bank pass when more than 16 are left
 #define PIO_PROJECT_Q32 1
 #endif
+#ifndef PIO_PROJECT_RT32      // 16-row tiles per loop iteration of the 32-query form
+#define PIO_PROJECT_RT32 2
+#endif
 #ifndef PIO_PROJECT_NT
 #define PIO_PROJECT_NT 1
 #endif
@@ -74,25 +77,29 @@ __global__ __launch_bounds__(256) void k_row_inv_norm(const float* __restrict__ 
 // NQG = query groups of 16 per pass: 1 (256 threads, two workgroups per CU) or 2 (512 threads, one per CU: waves 0-3
 // take queries q0..q0+15, waves 4-7 the next 16, both on the SAME bank tile in LDS, so a pass over the bank serves 32
 // queries -- the pipeline projects two image batches per pass).
-template <int D, int NQG>
+// RT = 16-row tiles per loop iteration: 2 for the 32-query form (one workgroup per CU has no second workgroup to fill its
+// barriers, so it walks two tiles between them: GEMM1 of both, ONE reduction barrier, then soft-max + GEMM2 of each in
+// row order -- the same operations in the same order per tile, bit-identical to RT = 1).
+template <int D, int NQG, int RT>
 __global__ __launch_bounds__(256 * NQG, NQG == 1 ? 2 : 1) void k_project(const float* __restrict__ bank, const float* __restrict__ inv_norm,
                                                     int64_t M, const float* __restrict__ q, int N, int q0,
                                                     float temperature, float* part_acc, float* part_ml, int parts) {
   constexpr int STRIDE = D + 4;                  // floats; +16 B skews rows across the 64 banks
   constexpr int DW = D / 4;                      // channels per wave
   constexpr int NT = 256 * NQG;                  // threads
-  constexpr int NV = D / 4 * PR_ROWS / NT;       // float4 per thread per tile
+  constexpr int ROWS = PR_ROWS * RT;             // bank rows staged per iteration
+  constexpr int NV = D / 4 * ROWS / NT;          // float4 per thread per iteration
   constexpr int NQ = PR_Q * NQG;                 // queries per pass
-  static_assert(D % 64 == 0 && (D / 4 * PR_ROWS) % NT == 0, "D");
+  static_assert(D % 64 == 0 && (D / 4 * ROWS) % NT == 0, "D");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* s_bank = lds;                            // [16][STRIDE]  (single buffer: two workgroups share a CU)
+  float* s_bank = lds;                            // [ROWS][STRIDE]  (single buffer: two workgroups share a CU)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = (tid >> 6) & 3, grp = tid >> 8;  // channel slice of the wave, query group of the wave
-  float* s_red = lds + PR_ROWS * STRIDE + grp * 4 * 256;   // [NQG][4][256]
+  float* s_red = lds + ROWS * STRIDE + grp * RT * 4 * 256;   // [NQG][RT][4][256]
   const int li = lane & 15, kq = lane >> 4;
 
   // slab of rows for this workgroup (multiple of 16 rows)
-  const int64_t tiles_total = (M + PR_ROWS - 1) / PR_ROWS;
+  const int64_t tiles_total = (M + ROWS - 1) / ROWS;
   const int64_t tiles_per = (tiles_total + parts - 1) / parts;
   const int64_t t_begin = (int64_t)blockIdx.x * tiles_per;
   int64_t t_end = t_begin + tiles_per;
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(256 * NQG, NQG == 1 ? 2 : 1) void k_project(const f
   // non-temporal: the bank is read once per call and is 7x the Infinity Cache; a default-policy stream evicts the
   // ViT / decoder weights that the next kernels want to find there
 #define PIO_BANK_SRC(t, i) \
-  ld_stream4(bank + (((t) * PR_ROWS + (tid + NT * (i)) / (D / 4)) < M ? ((t) * PR_ROWS + (tid + NT * (i)) / (D / 4)) : M - 1) * D + 4 * ((tid + NT * (i)) % (D / 4)))
+  ld_stream4(bank + (((t) * ROWS + (tid + NT * (i)) / (D / 4)) < M ? ((t) * ROWS + (tid + NT * (i)) / (D / 4)) : M - 1) * D + 4 * ((tid + NT * (i)) % (D / 4)))
 #define PIO_BANK_DST(buf, i) \
   (*(float4*)(s_bank + ((tid + NT * (i)) / (D / 4)) * STRIDE + 4 * ((tid + NT * (i)) % (D / 4))))
 #define PIO_LOAD_BANK(t)                                  \
@@ -162,66 +169,73 @@ __global__ __launch_bounds__(256 * NQG, NQG == 1 ? 2 : 1) void k_project(const f
   for (int64_t t = t_begin; t < t_end; ++t) {
     const int64_t tn = t + 1 < t_end ? t + 1 : t;   // last iteration: reloads its own tile (stored, never read)
     PIO_LOAD_BANK(tn)
-    const float* sb = s_bank;
-    // ---- GEMM1: partial S[row][n] over this wave's channels ----
-    f32x4 sp = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // ---- GEMM1: partial S[row][n] over this wave's channels, every 16-row tile of the iteration ----
 #pragma unroll
-    for (int c = 0; c < DW / 16; ++c) {
-      const int d = wid * DW + 16 * c + 4 * kq;
-      const float4 a = *(const float4*)(sb + li * STRIDE + d);
-      const float4 b = qreg[c];
-      sp = mfma16(a.x, b.x, sp);
-      sp = mfma16(a.y, b.y, sp);
-      sp = mfma16(a.z, b.z, sp);
-      sp = mfma16(a.w, b.w, sp);
+    for (int r = 0; r < RT; ++r) {
+      const float* sb = s_bank + r * PR_ROWS * STRIDE;
+      f32x4 sp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < DW / 16; ++c) {
+        const int d = wid * DW + 16 * c + 4 * kq;
+        const float4 a = *(const float4*)(sb + li * STRIDE + d);
+        const float4 b = qreg[c];
+        sp = mfma16(a.x, b.x, sp);
+        sp = mfma16(a.y, b.y, sp);
+        sp = mfma16(a.z, b.z, sp);
+        sp = mfma16(a.w, b.w, sp);
+      }
+      *(f32x4*)(s_red + (r * 4 + wid) * 256 + lane * 4) = sp;
     }
-    *(f32x4*)(s_red + wid * 256 + lane * 4) = sp;
     __syncthreads();
-    f32x4 sfull = *(const f32x4*)(s_red + lane * 4);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      const f32x4 o = *(const f32x4*)(s_red + w * 256 + lane * 4);
-      sfull += o;
-    }
-    // ---- online softmax for query n = li; this lane's rows are 4*kq + i ----
-    float p[4];
-    float tmax = -INFINITY;
+    for (int r = 0; r < RT; ++r) {
+      const float* sb = s_bank + r * PR_ROWS * STRIDE;
+      f32x4 sfull = *(const f32x4*)(s_red + (r * 4) * 256 + lane * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t row = t * PR_ROWS + 4 * kq + i;
-      float z = -INFINITY;
-      if (row < M) z = (sfull[i] * inv_norm[row]) / temperature;
-      p[i] = z;
-      tmax = fmaxf(tmax, z);
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float m_new = fmaxf(m_run, tmax);       // finite: every tile has at least one valid row
-    const float alpha = expf(m_run - m_new);      // exp(-inf) = 0 on the first tile
-    float rs = 0.f;
+      for (int w = 1; w < 4; ++w) {
+        const f32x4 o = *(const f32x4*)(s_red + (r * 4 + w) * 256 + lane * 4);
+        sfull += o;
+      }
+      // ---- online softmax for query n = li; this lane's rows are 4*kq + i ----
+      float p[4];
+      float tmax = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      p[i] = expf(p[i] - m_new);
-      rs += p[i];
-    }
-    rs += __shfl_xor(rs, 16);
-    rs += __shfl_xor(rs, 32);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-    // Acc[n][d]: this lane's register i belongs to query n = 4*kq + i -> fetch that query's alpha
-    float al[4];
+      for (int i = 0; i < 4; ++i) {
+        const int64_t row = t * ROWS + r * PR_ROWS + 4 * kq + i;
+        float z = -INFINITY;
+        if (row < M) z = (sfull[i] * inv_norm[row]) / temperature;
+        p[i] = z;
+        tmax = fmaxf(tmax, z);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run, tmax);       // finite from the first tile on (a slab's first tile has a valid row)
+      const float alpha = expf(m_run - m_new);      // exp(-inf) = 0 on the first tile
+      float rs = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) al[i] = __shfl(alpha, 4 * kq + i);
-    // ---- GEMM2: Acc[n][d] = Acc*alpha + P^T . bank ----
+      for (int i = 0; i < 4; ++i) {
+        p[i] = expf(p[i] - m_new);
+        rs += p[i];
+      }
+      rs += __shfl_xor(rs, 16);
+      rs += __shfl_xor(rs, 32);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+      // Acc[n][d]: this lane's register i belongs to query n = 4*kq + i -> fetch that query's alpha
+      float al[4];
 #pragma unroll
-    for (int j = 0; j < DW / 16; ++j) {
-      f32x4 a4 = acc[j];
+      for (int i = 0; i < 4; ++i) al[i] = __shfl(alpha, 4 * kq + i);
+      // ---- GEMM2: Acc[n][d] = Acc*alpha + P^T . bank ----
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a4[i] *= al[i];
-      const float* bp = sb + (4 * kq) * STRIDE + wid * DW + 16 * j + li;
+      for (int j = 0; j < DW / 16; ++j) {
+        f32x4 a4 = acc[j];
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) a4 = mfma16(p[tt], bp[tt * STRIDE], a4);
-      acc[j] = a4;
+        for (int i = 0; i < 4; ++i) a4[i] *= al[i];
+        const float* bp = sb + (4 * kq) * STRIDE + wid * DW + 16 * j + li;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) a4 = mfma16(p[tt], bp[tt * STRIDE], a4);
+        acc[j] = a4;
+      }
     }
     __syncthreads();                 // every wave is done reading this tile
     PIO_STORE_BANK(0)
@@ -344,14 +358,15 @@ __global__ __launch_bounds__(256) void k_revert(const float* __restrict__ x, con
 
 template <int D, int NQG>
 static hipError_t project_pass(const ProjectArgs& a, int q0, int parts, hipStream_t s) {
-  const int smem = (PR_ROWS * (D + 4) + NQG * 4 * 256) * (int)sizeof(float);
+  constexpr int RT = NQG == 2 ? PIO_PROJECT_RT32 : 1;
+  const int smem = (RT * PR_ROWS * (D + 4) + NQG * RT * 4 * 256) * (int)sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_project<D, NQG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)k_project<D, NQG, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_project<D, NQG>), dim3(parts), dim3(256 * NQG), smem, s, a.bank, a.inv_norm, a.M, a.q, a.N, q0,
+  hipLaunchKernelGGL((k_project<D, NQG, RT>), dim3(parts), dim3(256 * NQG), smem, s, a.bank, a.inv_norm, a.M, a.q, a.N, q0,
                      a.temperature, a.part_acc, a.part_ml, parts);
   return hipGetLastError();
 }

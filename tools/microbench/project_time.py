@@ -10,7 +10,7 @@ g = torch.Generator(device="cuda").manual_seed(6)
 M = 591753
 bank = torch.randn(M, 768, device="cuda", generator=g)
 e.set_memory_bank(bank)
-for N in (16, 32, 48, 64, 128):
+for N in ([int(a) for a in sys.argv[1:]] or (16, 32, 48, 64, 128)):
     q = torch.randn(N, 768, device="cuda", generator=g)
     for _ in range(3): out = e.project(q.clone(), normalize=True)
     torch.cuda.synchronize(); t = time.perf_counter()
