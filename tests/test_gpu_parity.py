@@ -301,6 +301,11 @@ def test_decoder_batch_sizes_and_graph_reuse(golden, eng224):
     for _ in range(2):
         ids, _ = eng224.decode_greedy(big)
         assert np.array_equal(ids.cpu().numpy(), np.tile(want, (5, 1)))
+    # every tile shape of the tiled layer GEMMs (k_dec_gemm_b: 2, 3..4 row groups here, 5..8 in the 128-prefix test), with a
+    # partial last row block
+    for N in (17, 32, 40, 48, 63):
+        ids, _ = eng224.decode_greedy(big[:N])
+        assert np.array_equal(ids.cpu().numpy(), np.tile(want, (5, 1))[:N]), N
 
 
 def test_decoder_128_prefixes_in_one_call(golden):
