@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--stage-streams", type=int, default=int(os.environ.get("PIO_BENCH_STAGE_STREAMS", "1")),
                     help="mode=group: model replicas (own ViT workspace, own stream) that stage 1 alternates over")
     ap.add_argument("--decode-streams", type=int, default=int(os.environ.get("PIO_BENCH_DECODE_STREAMS", "3")),
-                    help="mode=group: model replicas (own decoder workspace, own stream) that consecutive groups' decodes alternate over")
+                    help="mode=group: decoders (the model's own + clones on the same weights, each with its own workspace and stream) that consecutive groups' decodes alternate over")
     ap.add_argument("--vit-batches", type=int, default=int(os.environ.get("PIO_BENCH_VIT_BATCHES", "4")),
                     help="mode=group: consecutive bs-16 batches that share one ViT launch (1 = a launch per batch)")
     args = ap.parse_args()
@@ -115,7 +115,7 @@ def main():
     S = max(1, args.stage_streams)
     VB = max(1, min(args.vit_batches, P)) if args.mode == "group" else 1
     DS = max(1, args.decode_streams)
-    models = build_models(local, P if args.mode == "streams" else max(S, DS),
+    models = build_models(local, P if args.mode == "streams" else S,
                           max_prefixes=min(128, max(64, BATCH * P)) if args.mode == "group" else 64, max_batch=BATCH * VB)
     model = models[0]
     streams = [torch.cuda.Stream() for _ in range(P)]
@@ -129,7 +129,7 @@ def main():
     pipe = None
     if args.mode == "group" and P > 1:
         from patchioner_amd.pipeline import TraceCaptionPipeline
-        pipe = TraceCaptionPipeline(model, group_batches=P, stage_replicas=models[1:S], vit_batches=VB, decode_replicas=models[1:DS],
+        pipe = TraceCaptionPipeline(model, group_batches=P, stage_replicas=models[1:S], vit_batches=VB, decode_clones=DS - 1,
                                     stage_cus=int(os.environ.get("PIO_STAGE_CUS", "0")) or None,
                                     decode_cus=int(os.environ.get("PIO_DECODE_CUS", "0")) or None)
 
@@ -279,7 +279,7 @@ def main():
             "config": {"workload": "talk2dino_decap_COCO, ViT-B/14-reg 224^2, batch 16/GPU, caption_from=patches "
                                    "(one 16-patch trace region per image), bank 591753x768 fp32, 30-step greedy decode",
                        "global_batch": BATCH * world, "parallelism": "dp%d (image shards, ids all-gather)" % world, "batches_in_flight_per_gpu": P, "batches_per_vit_launch": VB, "concurrent_decodes": DS if args.mode == "group" else 1,
-                       "pipelining": "none" if P == 1 else ("one decode per %d batches (up to %d decodes in flight, one engine replica and stream each), overlapped with the next batches' ViT (one launch per %d batches) on %d stream(s)" % (P, DS, VB, S)
+                       "pipelining": "none" if P == 1 else ("one decode per %d batches (up to %d decodes in flight, one decoder clone and stream each), overlapped with the next batches' ViT (one launch per %d batches) on %d stream(s)" % (P, DS, VB, S)
                                                            if args.mode == "group" else "%d forwards on %d streams" % (P, P))},
             "roofline": roof,
             "roofline_sync": roof_sync,

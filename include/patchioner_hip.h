@@ -86,6 +86,12 @@ int pio_stream_destroy(void* stream);
 /* -- a1: construction (replaces Patchioner.__init__ / from_config, P/src/model.py:98-662, 666-715) -- */
 int pio_create(const pio_config* cfg, pio_handle* out);
 int pio_destroy(pio_handle h);
+/* A second decoder on the SAME weights (no reference counterpart; the reference decodes one batch at a time,
+ * P/src/decap/decap.py:116-183): a handle that borrows `src`'s finalized decoder weights (read-only, not copied) and
+ * owns its own activations, KV caches, scratch and decode graphs, so that pio_decode_greedy calls on `src` and on its
+ * clones may run concurrently on different streams (pipeline.py decodes consecutive groups of prefixes that way).
+ * Only pio_decode_greedy (and pio_destroy) are meaningful on a clone; `src` cannot be destroyed before its clones. */
+int pio_clone_decoder(pio_handle src, pio_handle* out);
 
 /* Upload one fp32 host tensor under its checkpoint key.  Keys are the reference checkpoints' own:
  *   backbone: "cls_token", "pos_embed", "register_tokens", "patch_embed.proj.weight", ...,

@@ -45,6 +45,7 @@ SIGNATURES = {
     "pio_stream_destroy": (c_int32, [c_void_p]),
     "pio_create": (c_int32, [POINTER(PioConfig), POINTER(c_void_p)]),
     "pio_destroy": (c_int32, [c_void_p]),
+    "pio_clone_decoder": (c_int32, [c_void_p, POINTER(c_void_p)]),
     "pio_load_weight": (c_int32, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int32]),
     "pio_finalize_weights": (c_int32, [c_void_p]),
     "pio_set_memory_bank": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, POINTER(c_int64)]),

@@ -81,6 +81,8 @@ struct pio_context {
   bool finalized = false, has_vit = false, has_dec = false, has_inv = false;
   std::unordered_map<std::string, HostTensor> host;
   std::vector<void*> allocs;
+  pio_context* parent = nullptr;   // pio_clone_decoder: the handle whose decoder weights this one borrows
+  int clones = 0;                  // live decoder clones of this handle (it cannot be destroyed before them)
 
   // ViT weights
   void* pe_w = nullptr; float* pe_b = nullptr; float* pos = nullptr; float* cls = nullptr; float* reg = nullptr;
@@ -290,6 +292,8 @@ int upload_ln_folded(pio_context* c, const float* W, bool in_major, int64_t in, 
   return upload_f32(c, dv.data(), dv.size(), dd);
 }
 
+int alloc_decoder_workspaces(pio_context* c);
+
 int finalize_decoder(pio_context* c) {
   const int E = c->cfg.dec_embd, V = c->cfg.dec_vocab, P = c->cfg.dec_positions, L = c->cfg.dec_layers;
   const int PS = c->cfg.prefix_size;
@@ -373,6 +377,15 @@ int finalize_decoder(pio_context* c) {
     w.fc2_b = dw;
   }
   HIP_OK(decoder_init());
+  if ((rc = alloc_decoder_workspaces(c))) return rc;
+  c->has_dec = true;
+  return PIO_OK;
+}
+
+// the decoder's per-handle state: activations, KV caches, split-K slabs, head scratch, staging buffers
+int alloc_decoder_workspaces(pio_context* c) {
+  int rc;
+  const size_t E = c->cfg.dec_embd, V = c->cfg.dec_vocab, L = c->cfg.dec_layers, PS = c->cfg.prefix_size;
   const size_t N = c->cfg.max_prefixes, S = c->cfg.max_steps;
   if ((rc = c->dmalloc(&c->dx, N * E, true))) return rc;
   if ((rc = c->dmalloc(&c->dqkv, N * 3 * E, true))) return rc;
@@ -389,7 +402,6 @@ int finalize_decoder(pio_context* c) {
   if ((rc = c->dmalloc(&c->prefix_buf, N * PS, true))) return rc;
   if ((rc = c->dmalloc(&c->logprob_buf, N * S, true))) return rc;
   if ((rc = c->dmalloc(&c->ids_buf, N * S, true))) return rc;
-  c->has_dec = true;
   return PIO_OK;
 }
 
@@ -528,8 +540,43 @@ int pio_create(const pio_config* cfg, pio_handle* out) {
   return PIO_OK;
 }
 
+int pio_clone_decoder(pio_handle src, pio_handle* out) {
+  if (!src || !out) return fail(PIO_ERR_INVALID_ARG, "pio_clone_decoder: null argument");
+  if (!src->finalized || !src->has_dec) return fail(PIO_ERR_NOT_READY, "pio_clone_decoder: decoder weights not finalized");
+  if (src->parent) return fail(PIO_ERR_INVALID_ARG, "pio_clone_decoder: clone the owner of the weights, not a clone");
+  HIP_OK(hipSetDevice(src->cfg.device));
+  pio_context* c = new pio_context();
+  c->cfg = src->cfg;
+  c->n = src->n; c->n2 = src->n2; c->T = src->T; c->Tp = src->Tp; c->Tk = src->Tk; c->G = src->G; c->D = src->D;
+  c->Kpe = src->Kpe; c->Kpad = src->Kpad; c->H = src->H; c->op = src->op;
+  c->use_graph = src->use_graph;
+  // borrowed, read-only: the decoder's weights (freed by the owner only)
+  c->clip_w = src->clip_w; c->clip_b = src->clip_b; c->wte = src->wte; c->wpe = src->wpe;
+  c->head_w = src->head_w; c->head_c = src->head_c; c->head_d = src->head_d;
+  c->head_w16 = src->head_w16; c->head_w16_unscale = src->head_w16_unscale; c->head_bound_coef = src->head_bound_coef;
+  c->dl = src->dl;
+  hipError_t e = hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return fail(PIO_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+  const int rc = alloc_decoder_workspaces(c);
+  if (rc != PIO_OK) {
+    for (void* p : c->allocs) (void)hipFree(p);
+    (void)hipStreamDestroy(c->capture_stream);
+    delete c;
+    return rc;
+  }
+  HIP_OK(hipDeviceSynchronize());   // the zero-fills above are done before any stream touches the new workspaces
+  c->has_dec = true;
+  c->finalized = true;
+  c->parent = src;
+  src->clones += 1;
+  *out = c;
+  return PIO_OK;
+}
+
 int pio_destroy(pio_handle c) {
   if (!c) return PIO_OK;
+  if (c->clones > 0) return fail(PIO_ERR_INVALID_ARG, "pio_destroy: decoder clones of this handle are still alive");
+  if (c->parent) c->parent->clones -= 1;
   (void)hipSetDevice(c->cfg.device);
   (void)hipDeviceSynchronize();
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);

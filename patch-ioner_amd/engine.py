@@ -65,6 +65,11 @@ class Engine:
         except Exception:
             pass
 
+    def clone_decoder(self) -> "DecoderClone":
+        """A second greedy decoder on this engine's weights (pio_clone_decoder): own KV caches / scratch / graphs, so its
+        decode_greedy may run concurrently with this engine's on another stream.  Close it before this engine."""
+        return DecoderClone(self)
+
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False) -> List[str]:
         """Upload fp32 tensors under their checkpoint keys; returns the keys the library does not know."""
@@ -317,3 +322,29 @@ class Engine:
             check(self.lib.pio_decode_greedy(self.h, ptr(prefix[s:e]), e - s, steps, ptr(ids[s:e]),
                                              ptr(lp[s:e]) if want_logprob else None, _stream()))
         return ids, lp
+
+
+
+class DecoderClone:
+    """Handle from pio_clone_decoder: borrows the parent's decoder weights, owns its workspaces.  Only decode_greedy."""
+
+    def __init__(self, parent: Engine):
+        self.lib, self.parent, self.device = parent.lib, parent, parent.device
+        self.max_prefixes, self.max_steps, self.prefix_size = parent.max_prefixes, parent.max_steps, parent.prefix_size
+        h = ctypes.c_void_p()
+        check(self.lib.pio_clone_decoder(parent.h, ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.pio_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    _dev = Engine._dev
+    decode_greedy = Engine.decode_greedy

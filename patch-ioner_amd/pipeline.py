@@ -15,8 +15,8 @@ the big ViT GEMMs leave).  ``vit_batches`` consecutive batches may also share on
 118 us per image at 16 images per launch, 86 us at 48 and more: fewer GEMM tails and launch gaps; the model's
 ``max_batch`` must cover them).  The token ids are bit-identical to the synchronous path either way (every ViT
 output element is computed in the same order whatever the launch holds; the decoder is exact fp32 and
-row-independent); captions come back per batch, in order.  ``decode_replicas`` lets consecutive groups decode
-concurrently (each on its own engine replica and stream): next to stage 1 a decode stretches about 2x, and with three
+row-independent); captions come back per batch, in order.  ``decode_clones`` / ``decode_replicas`` let consecutive groups decode
+concurrently (each on its own decoder -- a clone on the same weights, or a replica -- and stream): next to stage 1 a decode stretches about 2x, and with three
 in flight stage 1 never waits for a group buffer.
 """
 from __future__ import annotations
@@ -47,7 +47,7 @@ class TraceCaptionPipeline:
 
     def __init__(self, model, group_batches: int = 4, use_attention_tracing: bool = False, steps: int = 30,
                  stage_replicas: Sequence = (), stage_cus: Optional[int] = None, decode_cus: Optional[int] = None,
-                 vit_batches: int = 1, decode_replicas: Sequence = ()):
+                 vit_batches: int = 1, decode_replicas: Sequence = (), decode_clones: int = 0):
         """``stage_replicas``: further Patchioner instances holding the SAME weights (each has its own ViT
         workspace); stage 1 of consecutive batches then alternates over the replicas, each on its own stream,
         so that one batch's GEMM tails, epilogues and launch gaps are filled by the other's kernels."""
@@ -56,7 +56,10 @@ class TraceCaptionPipeline:
         # ``decode_replicas``: further instances (same weights, own decoder workspace) so that consecutive groups'
         # decodes run concurrently, each on its own stream: a decode is a chain of ~660 small dependent kernels that
         # stretches 2x when it shares the chip with stage 1, and two chains in flight hide each other's waits.
-        self.decode_engines = [model.engine] + [r.engine for r in decode_replicas]
+        # ``decode_clones`` makes them here: decoders on the model's OWN weights (Engine.clone_decoder: borrowed weights, own
+        # KV caches / scratch / graphs) -- no second copy of the weights or the bank, unlike whole-model replicas.
+        self._own_clones = [model.engine.clone_decoder() for _ in range(max(0, int(decode_clones)))]
+        self.decode_engines = [model.engine] + [getattr(r, "engine", r) for r in decode_replicas] + self._own_clones
         self.group_batches = group_batches
         self.vit_batches = max(1, int(vit_batches))
         self._held: List = []             # batches waiting for their shared ViT launch
@@ -107,6 +110,12 @@ class TraceCaptionPipeline:
         for raw in self._raw_streams:
             load().pio_stream_destroy(raw)
         self._raw_streams = []
+        for c in self._own_clones:
+            c.close()
+        self.decode_engines = self.decode_engines[:len(self.decode_engines) - len(self._own_clones)]
+        self._own_clones = []
+        self.decode_streams = self.decode_streams[:len(self.decode_engines)]
+        self.groups = self.groups[:1 + len(self.decode_engines)]
 
     # ---- stage 1: everything up to the decoder prefix, on stream A ------------------------------------
     def _stage(self, g: _Group, held: List) -> None:

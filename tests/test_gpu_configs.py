@@ -167,6 +167,12 @@ def test_grouped_decode_pipeline_matches_synchronous_forward():
     got = list(TraceCaptionPipeline(m, group_batches=2, vit_batches=2, decode_replicas=reps).run((imgs, None) for imgs, _ in batches))
     assert got == want
     del reps
+    # ... or on decoder clones (pio_clone_decoder: the model's own weights, separate KV caches / scratch / graphs)
+    pipe = TraceCaptionPipeline(m, group_batches=2, vit_batches=2, decode_clones=2)
+    assert list(pipe.run((imgs, None) for imgs, _ in batches)) == want
+    from patchioner_amd._lib import load
+    assert load().pio_destroy(m.engine.h) < 0 and b"clones" in load().pio_last_error()    # the owner outlives its clones
+    pipe.close()
     # CU-masked streams (pio_stream_create): same captions; close() releases them and the pipeline stays usable
     pipe = TraceCaptionPipeline(m, group_batches=4, stage_cus=192, decode_cus=64)
     assert list(pipe.run((imgs, None) for imgs, _ in batches)) == want
@@ -298,9 +304,8 @@ def test_pipeline_soak_is_deterministic():
     m = _model(224, True, max_batch=32)
     imgs = W.synth_images(55, 16, 224).cuda()
     traces = [gc.block_trace(i % 13, (3 * i) % 13) for i in range(16)]
-    # the bench's shape: shared ViT launches, paired projections, three decodes in flight on engine replicas
-    reps = [_model(224, True, max_batch=32) for _ in range(2)]
-    pipe = TraceCaptionPipeline(m, group_batches=4, vit_batches=2, decode_replicas=reps)
+    # the bench's shape: shared ViT launches, paired projections, three decodes in flight (the engine and two decoder clones)
+    pipe = TraceCaptionPipeline(m, group_batches=4, vit_batches=2, decode_clones=2)
     first, seen, groups = None, None, 0
     for _ in pipe.run((imgs, traces) for _ in range(300)):
         if pipe.last_ids is not seen:
