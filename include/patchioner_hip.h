@@ -6,7 +6,7 @@
  * below therefore replaces a *Python* function (or an inline block of Patchioner.forward) and cites
  * it as P/<file>:<lines> with P = /root/reference/Patch-ioner.  The reference-side binding a
  * maintainer would add is the ctypes stub shown in INTEGRATION.md (and shipped as
- * patch-ioner_amd/_lib.py).
+ * patchioner_amd/_lib.py).
  *
  * Conventions
  *   - plain C: pointers and sizes only, no torch / HIP types (streams travel as void*).

@@ -1,9 +1,13 @@
-"""Import alias: the sources live in ``patch-ioner_amd/`` (a directory name python cannot import),
-this one-file package redirects ``import patchioner_amd[.x]`` there."""
-import os as _os
+"""patchioner_amd -- MI355X-native implementation of Patch-ioner's captioning hot path.
 
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "patch-ioner_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
-del _os, _f, _real
+Public surface mirrors the reference package (``from patchioner import Patchioner``,
+R/pyproject.toml:18-25; ``from src.model import Patchioner`` in the eval scripts).
+"""
+__version__ = "0.1.0"
+
+
+def __getattr__(name):  # lazy: importing the package must not require a GPU or the built library
+    if name == "Patchioner":
+        from .model import Patchioner
+        return Patchioner
+    raise AttributeError(name)

@@ -88,7 +88,7 @@ def load() -> ctypes.CDLL:
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise PioError(-100, "%s not found: run `python patch-ioner_amd/build.py` (hipcc, gfx950); "
+        raise PioError(-100, "%s not found: run `python patchioner_amd/build.py` (hipcc, gfx950); "
                              "there is no CPU fallback" % LIB_PATH)
     try:
         import torch  # noqa: F401  (loads libamdhip64 with the soname our library asks for)

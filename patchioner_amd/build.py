@@ -1,6 +1,6 @@
 """Builds libpatchioner_hip.so in-tree with hipcc for gfx950 (no cmake, no JIT cache).
 
-    python patch-ioner_amd/build.py [--force]
+    python patchioner_amd/build.py [--force]
 
 Objects are rebuilt only when a source or header is newer.  hipcc cross-compiles without a GPU.
 """

@@ -98,8 +98,8 @@ def test_inline_asm_weight_loads_are_not_touched_before_their_wait(tmp_path):
     import sys
     asm = tmp_path / "decoder.s"
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-I", os.path.join(ROOT, "include"),
-                    "-I", os.path.join(ROOT, "patch-ioner_amd", "csrc"), "-S", "--cuda-device-only",
-                    os.path.join(ROOT, "patch-ioner_amd", "csrc", "decoder.hip"), "-o", str(asm)], check=True)
+                    "-I", os.path.join(ROOT, "patchioner_amd", "csrc"), "-S", "--cuda-device-only",
+                    os.path.join(ROOT, "patchioner_amd", "csrc", "decoder.hip"), "-o", str(asm)], check=True)
     text = asm.read_text()
     names = sorted(set(re.findall(r"^(_ZN3pio\d+k_lmhead_(?:wide|f16)\w+):", text, flags=re.M)))
     assert len(names) == 8, names        # k_lmhead_wide<1,2,4>, k_lmhead_f16<1,2,4,8>, k_lmhead_f16_fused

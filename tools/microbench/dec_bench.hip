@@ -1,8 +1,8 @@
 // Stand-alone timing of the decoder kernels (diagnostic, never shipped):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I patch-ioner_amd/csrc tools/microbench/dec_bench.hip -o dec_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I patchioner_amd/csrc tools/microbench/dec_bench.hip -o dec_bench
 // Each kernel is launched in a dependent chain of ITER launches on one stream (like the decode graph) and the
 // per-launch time is the elapsed time / ITER.
-#include "../../patch-ioner_amd/csrc/decoder.hip"
+#include "../../patchioner_amd/csrc/decoder.hip"
 #include <cstdio>
 #include <cstring>
 #include <vector>

@@ -1,6 +1,6 @@
 // Stand-alone timing of k_vit_gemm with parts compiled out (diagnostic build, never shipped):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I patch-ioner_amd/csrc [-DPIO_ABL_x] tools/microbench/gemm_ablate.hip
-#include "../../patch-ioner_amd/csrc/vit_gemm.hip"
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I patchioner_amd/csrc [-DPIO_ABL_x] tools/microbench/gemm_ablate.hip
+#include "../../patchioner_amd/csrc/vit_gemm.hip"
 #include <cstdio>
 #include <cstring>
 #include <vector>

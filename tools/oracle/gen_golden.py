@@ -184,7 +184,7 @@ def gen_tokenizer(ref):
     offs = np.zeros(len(table) + 1, dtype=np.uint32)
     offs[1:] = np.cumsum([len(t) for t in table])
     blob = np.frombuffer(b"".join(table), dtype=np.uint8)
-    asset = os.path.join(ROOT, "patch-ioner_amd", "assets")
+    asset = os.path.join(ROOT, "patchioner_amd", "assets")
     os.makedirs(asset, exist_ok=True)
     np.savez_compressed(os.path.join(asset, "clip_bpe_decode_table.npz"), offsets=offs, blob=blob)
     save("tokenizer", ids=np.asarray([r + [-1] * (30 - len(r)) for r in rows], dtype=np.int64),

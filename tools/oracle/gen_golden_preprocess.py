@@ -1,6 +1,6 @@
 """Golden vectors for the image transforms, made with Pillow itself (the third-party code behind the reference's
 torchvision Resize; P/src/model.py:347-357): small seeded images, PIL.Image.resize(..., BICUBIC) outputs, and the full
-transform through the size rules of torchvision restated in patch-ioner_amd/preprocess.py.
+transform through the size rules of torchvision restated in patchioner_amd/preprocess.py.
     python tools/oracle/gen_golden_preprocess.py   ->  tests/golden/preprocess.npz"""
 import os
 import sys
