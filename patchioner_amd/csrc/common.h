@@ -44,6 +44,26 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// GELU(v) = 0.5 v (1 + erf(v / sqrt 2)), the exact-erf form DINOv2's MLP uses, to 7.5e-7 absolute (fp32 evaluation,
+// checked against scipy on [-12, 12]; the result is rounded to fp16/bf16 anyway).  erfc(t) = 2^(-t q(t)) with a degree-5
+// polynomial q fitted on [0, 4.3] (least squares weighted for the absolute error of erf; erfc(4.3) = 1.2e-9).  With
+// u = min(|v|, 4.3 sqrt 2), E = 2^-(1 + u q'(u)) = erfc(u / sqrt 2) / 2 (q' = q rescaled to the argument v) and h = v E:
+//     GELU(v) = max(v, 0) - |h|          (v > 0: v - v E;  v < 0: v E)
+// One transcendental (v_exp_f32) and 11 plain VALU instructions per element; the Abramowitz-Stegun 7.1.26 form it
+// replaces needed v_rcp + v_exp + 16 (the epilogue of the fc1 GEMM is VALU-bound: 64 Ki elements per 256 x 256 tile).
+// NaN in, NaN out; +-inf gives NaN (activations are finite: the operand type saturates long before).
+__device__ __forceinline__ float gelu_erf(float v) {
+  const float u = fminf(fabsf(v), 6.0811183f);
+  float q = -1.971039006e-05f;
+  q = fmaf(q, u, 6.613329563e-04f);
+  q = fmaf(q, u, -7.757447031e-03f);
+  q = fmaf(q, u, 5.296219534e-02f);
+  q = fmaf(q, u, 4.590671448e-01f);
+  q = fmaf(q, u, 1.151118979e+00f);
+  const float h = v * __builtin_amdgcn_exp2f(-fmaf(u, q, 1.0f));
+  return fmaxf(v, 0.f) - fabsf(h);
+}
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

@@ -34,6 +34,9 @@ struct GemmArgs {
 };
 
 hipError_t launch_vit_gemm(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
+// 256 x 256 tiles, 8 waves (vit_gemm256.hip): same arithmetic per output element; launch_vit_gemm dispatches to it
+bool vit_gemm256_fits(GemmEpilogue epi, const GemmArgs& a);
+hipError_t launch_vit_gemm256(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
 
 struct VitAttnArgs {
   const void* q; const void* k; const void* vT;  // as written by EPI_QKV

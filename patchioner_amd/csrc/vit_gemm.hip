@@ -19,6 +19,7 @@
 // Workgroup ids are remapped so that each XCD's L2 sees a contiguous run of tiles sharing A panels.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace pio {
 
@@ -42,17 +43,6 @@ static constexpr int BN = 128, BK = 64;
 #ifndef PIO_GEMM_BM_NARROW      // tile height used when N == D (proj, fc2, patch embed)
 #define PIO_GEMM_BM_NARROW 64
 #endif
-
-// erf to 1.5e-7 absolute (Abramowitz-Stegun 7.1.26): one v_rcp + one v_exp + 7 FMAs instead of libdevice's
-// branchy erff; the result is rounded to fp16/bf16 anyway.
-__device__ __forceinline__ float erf_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
-  const float r = 1.0f - poly * __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
-  return copysignf(r, x);
-}
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f)); }
 
 template <typename T>
 __device__ __forceinline__ void store_half4(T* dst, float a, float b, float c, float d) {
@@ -357,7 +347,14 @@ static hipError_t launch_typed(GemmEpilogue epi, const GemmArgs& a, hipStream_t 
   return hipErrorInvalidValue;
 }
 
+// rows from which the 256 x 256 kernel (vit_gemm256.hip) takes over; PIO_GEMM256_MIN_M overrides (0 = never)
+static int gemm256_min_m() {
+  static const int v = [] { const char* e = getenv("PIO_GEMM256_MIN_M"); return e ? atoi(e) : 8192; }();
+  return v;
+}
+
 hipError_t launch_vit_gemm(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
+  if (gemm256_min_m() > 0 && a.M >= gemm256_min_m() && vit_gemm256_fits(epi, a)) return launch_vit_gemm256(t, epi, a, s);
   if (a.M <= 0 || a.N % BN != 0 || a.K % (2 * BK) != 0 || a.lda % 8 != 0) return hipErrorInvalidValue;
   // the staging offsets are 32-bit byte offsets from A and W
   if ((size_t)a.M * a.lda * 2 >= ((size_t)1 << 32) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;

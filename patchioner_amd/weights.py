@@ -73,6 +73,24 @@ def synth_dinov2(seed: int, dino_model: str = "dinov2_vitb14_reg", depth: int | 
     return w
 
 
+def add_outlier_channels(w: Dict[str, torch.Tensor], channels=(7, 300, 611), block: int = 1, gain: float = 4000.0,
+                         hidden_rows=(11, 2000), hidden_gain: float = 30.0) -> Dict[str, torch.Tensor]:
+    """DINOv2-like massive activations for stress tests: the MLP branch of ``block`` is multiplied by ``gain`` on a few
+    channels (from there on the fp32 residual stream carries values in the hundreds on those channels and every later
+    LayerNorm sees a few dominant channels), and a few hidden units of every later MLP get ``hidden_gain``-times larger
+    pre-activations (large fc2 operands).  Returns a modified copy."""
+    w = dict(w)
+    depth = 1 + max(int(k.split(".")[1]) for k in w if k.startswith("blocks."))
+    g2 = w["blocks.%d.ls2.gamma" % block].clone()
+    g2[list(channels)] *= gain
+    w["blocks.%d.ls2.gamma" % block] = g2
+    for i in range(block + 1, depth):
+        f = w["blocks.%d.mlp.fc1.weight" % i].clone()
+        f[list(hidden_rows)] *= hidden_gain
+        w["blocks.%d.mlp.fc1.weight" % i] = f
+    return w
+
+
 def synth_decap(seed: int, prefix_size: int = 768, n_layer: int = 4, n_embd: int = 768,
                 vocab: int = 50257, n_positions: int = 1024, tok_vocab: int = 49408,
                 std: float = 0.02) -> Dict[str, torch.Tensor]:

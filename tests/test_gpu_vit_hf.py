@@ -1,0 +1,69 @@
+"""The HIP ViT against the INDEPENDENT HF port of DINOv2-with-registers at full depth (the backbone's
+arithmetic is third-party and absent from the reference tree, so this is the strongest pin available for row a2).
+
+tests/golden/vit_hf_depth12.npz holds transformers.Dinov2WithRegistersModel outputs (fp32, CPU, eager attention) for our
+seeded 12-block state dict mapped into its layout (tools/oracle/gen_golden.py: gen_vit_hf12): 224^2 and 518^2, plain
+weights and the outlier-channel variant (weights.add_outlier_channels: residual-stream channels in the hundreds, a few
+MLP hidden units 30x larger), the five global tokens and every 7th / 29th patch token of 2 images.
+
+Tolerances (max |err| / max |ref| over the compared tokens): fp16 operands 4e-3, bf16 3e-2 -- the same bars as the
+oracle comparison in test_gpu_parity.py; with the outlier weights the bar is stated against the fixture's own maximum
+(the outlier channels dominate it), plus a cosine bar per token that the small channels decide.
+"""
+import numpy as np
+import pytest
+import torch
+
+from patchioner_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def _tokens(sd, size, dtype, batch=2):
+    from patchioner_amd.engine import Engine
+    e = Engine(embed_dim=768, depth=12, num_heads=12, num_registers=4, crop_dim=size, max_batch=batch, vit_dtype=dtype)
+    try:
+        e.load_state_dict(sd)
+        e.finalize()
+        tokens, _ = e.vit_forward(W.synth_images(84, batch, size), want_qkv=False)
+        torch.cuda.synchronize()
+        return tokens.cpu()
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("size,stride", [(224, 7), (518, 29)])
+@pytest.mark.parametrize("dtype,tol", [("fp16", 4e-3), ("bf16", 3e-2)])
+def test_hip_vit_depth12_vs_hf_port(golden, size, stride, dtype, tol):
+    g = golden("vit_hf_depth12")
+    got = _tokens(W.synth_dinov2(83, depth=12), size, dtype)
+    ref = torch.cat([torch.from_numpy(g["plain%d_global" % size]), torch.from_numpy(g["plain%d_patch_sample" % size])], 1)
+    cmp = torch.cat([got[:, :5], got[:, 5::stride]], 1)
+    assert cmp.shape == ref.shape and torch.isfinite(got).all()
+    err = float((cmp - ref).abs().max() / ref.abs().max())
+    cos = float(torch.nn.functional.cosine_similarity(cmp, ref, dim=-1).min())
+    print("HF depth-12 %d^2 [%s]: rel-max-err %.2e, min cosine %.6f" % (size, dtype, err, cos))
+    assert err <= tol and cos >= 1 - 4 * tol * tol
+
+
+@pytest.mark.parametrize("size,stride", [(224, 7), (518, 29)])
+@pytest.mark.parametrize("dtype,tol", [("fp16", 4e-3), ("bf16", 3e-2)])
+def test_hip_vit_outlier_channels_vs_hf_port(golden, size, stride, dtype, tol):
+    """Residual-stream channels near 470 next to channels of order 0.4, hidden units 30x larger than the rest: the fp32
+    residual stream and fp32 LayerNorm statistics keep the fp16 / bf16 operand path finite and inside the same bar."""
+    g = golden("vit_hf_depth12")
+    sd = W.add_outlier_channels(W.synth_dinov2(83, depth=12))
+    got = _tokens(sd, size, dtype)
+    ref = torch.cat([torch.from_numpy(g["outlier%d_global" % size]), torch.from_numpy(g["outlier%d_patch_sample" % size])], 1)
+    cmp = torch.cat([got[:, :5], got[:, 5::stride]], 1)
+    assert torch.isfinite(got).all()
+    err = float((cmp - ref).abs().max() / ref.abs().max())
+    cos = float(torch.nn.functional.cosine_similarity(cmp, ref, dim=-1).min())
+    # the final LayerNorm rescales every token by its (outlier-dominated) deviation: also compare with the outlier
+    # channels masked out, relative to the largest remaining reference value
+    keep = torch.ones(768, dtype=torch.bool)
+    keep[[7, 300, 611]] = False
+    err_small = float((cmp[..., keep] - ref[..., keep]).abs().max() / ref[..., keep].abs().max())
+    print("HF outliers %d^2 [%s]: rel-max-err %.2e (other channels %.2e), min cosine %.6f" % (size, dtype, err, err_small, cos))
+    assert err <= tol and err_small <= 2 * tol and cos >= 1 - 4 * tol * tol

@@ -1,0 +1,227 @@
+// Stand-alone check + timing of k_vit_gemm256 against k_vit_gemm (diagnostic build, never shipped):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I patchioner_amd/csrc tools/microbench/gemm256_bench.hip -o tools/microbench/bin/gemm256_bench
+//   gemm256_bench [check|time|both] [B ...]
+// check: every output buffer of the new kernel compared bit for bit with the old kernel's (all epilogues, fp16 and bf16,
+//        with and without the fp32 qkv capture, a ragged last tile);  time: interleaved rounds, random operands.
+#define PIO_G256_ALL_VARIANTS 1
+#define PIO_G256_STAMPS 1
+#include "../../patchioner_amd/csrc/vit_gemm.hip"
+#include "../../patchioner_amd/csrc/vit_gemm256.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <random>
+#include <string>
+#include <vector>
+using namespace pio;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+static uint16_t f2h(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
+
+struct Bufs {
+  int B, T, Tp, Tk, D, H, n2, G, M, Kpad;
+  void *A, *A4, *Ape, *W, *Wpe, *out16, *q, *k, *v; float *bias, *x, *ls, *pos, *cap;
+  size_t sz_out16, sz_qk, sz_x, sz_cap;
+};
+
+static void fill16(void* dev, size_t n, bool bf, float scale, uint32_t seed) {
+  std::vector<uint16_t> h(n);
+  std::mt19937 rng(seed);
+  std::normal_distribution<float> nd(0.f, scale);
+  for (size_t i = 0; i < n; ++i) { const float f = nd(rng); h[i] = bf ? f2bf(f) : f2h(f); }
+  CK(hipMemcpy(dev, h.data(), n * 2, hipMemcpyHostToDevice));
+}
+static void fill32(float* dev, size_t n, float scale, float mean, uint32_t seed) {
+  std::vector<float> h(n);
+  std::mt19937 rng(seed);
+  std::normal_distribution<float> nd(mean, scale);
+  for (size_t i = 0; i < n; ++i) h[i] = nd(rng);
+  CK(hipMemcpy(dev, h.data(), n * 4, hipMemcpyHostToDevice));
+}
+
+static Bufs make(int B, int side, int D, bool bf) {
+  Bufs b; memset(&b, 0, sizeof(b));
+  b.B = B; b.D = D; b.H = D / 64; b.G = 5; b.n2 = side * side; b.T = b.G + b.n2; b.Tp = round_up(b.T, 8); b.Tk = round_up(b.T, 64);
+  b.M = B * b.Tp; b.Kpad = 640;
+  const size_t M = b.M;
+  CK(hipMalloc(&b.A, M * D * 2)); CK(hipMalloc(&b.A4, M * 4 * D * 2)); CK(hipMalloc(&b.Ape, (size_t)B * b.n2 * b.Kpad * 2));
+  CK(hipMalloc(&b.W, (size_t)4 * D * D * 2)); CK(hipMalloc(&b.Wpe, (size_t)D * b.Kpad * 2));
+  b.sz_out16 = M * 4 * D * 2; b.sz_qk = (size_t)B * b.H * b.Tk * 64 * 2; b.sz_x = M * D * 4; b.sz_cap = (size_t)B * b.T * 3 * D * 4;
+  CK(hipMalloc(&b.out16, b.sz_out16)); CK(hipMalloc(&b.q, b.sz_qk)); CK(hipMalloc(&b.k, b.sz_qk)); CK(hipMalloc(&b.v, b.sz_qk));
+  CK(hipMalloc(&b.bias, 4 * D * 4)); CK(hipMalloc(&b.x, b.sz_x)); CK(hipMalloc(&b.ls, D * 4));
+  CK(hipMalloc(&b.pos, (size_t)(1 + b.n2) * D * 4)); CK(hipMalloc(&b.cap, b.sz_cap));
+  fill16(b.A, M * D, bf, 1.0f, 1); fill16(b.A4, M * 4 * D, bf, 0.5f, 2); fill16(b.Ape, (size_t)B * b.n2 * b.Kpad, bf, 1.0f, 3);
+  fill16(b.W, (size_t)4 * D * D, bf, 0.03f, 4); fill16(b.Wpe, (size_t)D * b.Kpad, bf, 0.03f, 5);
+  fill32(b.bias, 4 * D, 0.1f, 0.f, 6); fill32(b.ls, D, 0.05f, 0.1f, 7); fill32(b.pos, (size_t)(1 + b.n2) * D, 0.02f, 0.f, 8);
+  return b;
+}
+static void release(Bufs& b) {
+  for (void* p : {b.A, b.A4, b.Ape, b.W, b.Wpe, b.out16, b.q, b.k, b.v, (void*)b.bias, (void*)b.x, (void*)b.ls, (void*)b.pos, (void*)b.cap}) CK(hipFree(p));
+}
+
+struct Case { const char* name; GemmEpilogue e; int which; };   // which: 0 qkv, 1 proj, 2 fc1, 3 fc2, 4 patch embed, 5 qkv + capture
+static GemmArgs args_for(const Bufs& b, const Case& c) {
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  const int D = b.D;
+  g.T = b.T; g.Tp = b.Tp; g.Tk = b.Tk; g.G = b.G; g.n2 = b.n2; g.D = D; g.H = b.H;
+  g.x = b.x; g.q = b.q; g.k = b.k; g.vT = b.v; g.bias = b.bias; g.ls = b.ls; g.out16 = b.out16; g.pos = b.pos;
+  g.M = b.M;
+  switch (c.which) {
+    case 0: case 5: g.A = b.A; g.lda = D; g.W = b.W; g.N = 3 * D; g.K = D; g.qkv_last = c.which == 5 ? b.cap : nullptr; break;
+    case 1: g.A = b.A; g.lda = D; g.W = b.W; g.N = D; g.K = D; break;
+    case 2: g.A = b.A; g.lda = D; g.W = b.W; g.N = 4 * D; g.K = D; break;
+    case 3: g.A = b.A4; g.lda = 4 * D; g.W = b.W; g.N = D; g.K = 4 * D; break;
+    case 4: g.A = b.Ape; g.lda = b.Kpad; g.W = b.Wpe; g.N = D; g.K = b.Kpad; g.M = b.B * b.n2; break;
+  }
+  return g;
+}
+static const Case CASES[] = {{"qkv ", EPI_QKV, 0}, {"proj", EPI_RESIDUAL, 1}, {"fc1 ", EPI_GELU, 2}, {"fc2 ", EPI_RESIDUAL, 3},
+                             {"pemb", EPI_PATCH_EMBED, 4}, {"qkvc", EPI_QKV, 5}};
+
+static std::vector<uint8_t> snapshot(const Bufs& b) {
+  std::vector<uint8_t> h(b.sz_out16 + 3 * b.sz_qk + b.sz_x + b.sz_cap);
+  size_t o = 0;
+  CK(hipMemcpy(h.data() + o, b.out16, b.sz_out16, hipMemcpyDeviceToHost)); o += b.sz_out16;
+  CK(hipMemcpy(h.data() + o, b.q, b.sz_qk, hipMemcpyDeviceToHost)); o += b.sz_qk;
+  CK(hipMemcpy(h.data() + o, b.k, b.sz_qk, hipMemcpyDeviceToHost)); o += b.sz_qk;
+  CK(hipMemcpy(h.data() + o, b.v, b.sz_qk, hipMemcpyDeviceToHost)); o += b.sz_qk;
+  CK(hipMemcpy(h.data() + o, b.x, b.sz_x, hipMemcpyDeviceToHost)); o += b.sz_x;
+  CK(hipMemcpy(h.data() + o, b.cap, b.sz_cap, hipMemcpyDeviceToHost));
+  return h;
+}
+static void reset_outputs(const Bufs& b) {
+  CK(hipMemset(b.out16, 0, b.sz_out16)); CK(hipMemset(b.q, 0, b.sz_qk)); CK(hipMemset(b.k, 0, b.sz_qk)); CK(hipMemset(b.v, 0, b.sz_qk));
+  CK(hipMemset(b.cap, 0, b.sz_cap));
+  fill32(b.x, b.sz_x / 4, 1.0f, 0.f, 9);
+}
+
+static const int NVAR = 2;
+static int check(int B, int side, int D, bool bf) {
+  Bufs b = make(B, side, D, bf);
+  const OperandType op = bf ? OP_BF16 : OP_F16;
+  int bad = 0;
+  for (const Case& c : CASES) {
+    GemmArgs g = args_for(b, c);
+    if (!vit_gemm256_fits(c.e, g)) { printf("  %s: shape not served by the 256 kernel\n", c.name); continue; }
+    reset_outputs(b);
+    CK(launch_vit_gemm(op, c.e, g, 0)); CK(hipDeviceSynchronize());
+    const std::vector<uint8_t> ref = snapshot(b);
+    size_t worst = 0;
+    for (int rep = 0; rep < 2 * NVAR; ++rep) {       // repeated: a race would not reproduce identically
+      reset_outputs(b);
+      CK(launch_vit_gemm256_variant(rep % NVAR, op, c.e, g, 0)); CK(hipDeviceSynchronize());
+      const std::vector<uint8_t> got = snapshot(b);
+      size_t nd = 0, first = 0;
+      for (size_t i = 0; i < ref.size(); ++i) if (ref[i] != got[i]) { if (!nd) first = i; ++nd; }
+      if (nd) printf("  %s rep %d: %zu differing bytes of %zu (first at %zu; out16 %zu | q | k | v %zu each | x %zu | cap)\n", c.name, rep, nd,
+                     ref.size(), first, b.sz_out16, b.sz_qk, b.sz_x);
+      worst = std::max(worst, nd);
+    }
+    // non-trivial output guard: the reference must have written something
+    size_t nz = 0; for (size_t i = 0; i < ref.size(); i += 97) nz += ref[i] != 0;
+    printf("  %s M=%d N=%d K=%d %s: %s (sampled non-zero bytes %zu)\n", c.name, g.M, g.N, g.K, bf ? "bf16" : "fp16",
+           worst ? "MISMATCH" : "bit-identical", nz);
+    bad += worst != 0;
+  }
+  release(b);
+  return bad;
+}
+
+static void time_all(int B, int side, int D) {
+  Bufs b = make(B, side, D, false);
+  CK(hipMemset(b.ls, 0, D * 4));              // x stays bounded over repeated residual launches
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int rounds = 7, it = 10;
+  printf("B=%d (M=%d), D=%d, T=%d      median us (TFLOP/s): old 128-tile kernel | 256 kernel, schedule 0 | schedule 1\n", B, b.M, D, b.T);
+  double tot[1 + NVAR] = {0, 0, 0}, totfl = 0;
+  for (const Case& c : CASES) {
+    GemmArgs g = args_for(b, c);
+    const bool fits = vit_gemm256_fits(c.e, g);
+    std::vector<float> tt[1 + NVAR];
+    for (int r = 0; r < rounds; ++r) {
+      for (int which = 0; which < 1 + NVAR; ++which) {
+        if (which >= 1 && !fits) continue;
+        auto go = [&]() { return which ? launch_vit_gemm256_variant(which - 1, OP_F16, c.e, g, 0) : launch_vit_gemm(OP_F16, c.e, g, 0); };
+        for (int i = 0; i < 2; ++i) CK(go());
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < it; ++i) CK(go());
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        tt[which].push_back(ms * 1e3f / it);
+      }
+    }
+    const double fl = 2.0 * g.M * (double)g.N * g.K;
+    printf("  %s %6dx%4dx%4d ", c.name, g.M, g.N, g.K);
+    const int mult = c.which <= 3 ? 12 : (c.which == 4 ? 1 : 0);   // launches per 12-block forward (11 + 1 qkv with capture ignored)
+    for (int which = 0; which < 1 + NVAR; ++which) {
+      if (tt[which].empty()) { printf(" |      -        "); continue; }
+      std::sort(tt[which].begin(), tt[which].end());
+      const double us = tt[which][tt[which].size() / 2];
+      printf(" | %7.1f (%5.0f)", us, fl / us / 1e6);
+      tot[which] += mult * us;
+    }
+    totfl += mult * fl;
+    printf("\n");
+  }
+  printf("  one 12-block forward: ");
+  for (int which = 0; which < 1 + NVAR; ++which) printf(" | %7.1f us (%5.0f TF)", tot[which], totfl / tot[which] / 1e6);
+  printf("\n");
+  release(b);
+}
+
+// where a tile's cycles go: s_memtime stamps of every workgroup (entry, first operands landed, main loop done, end)
+static void stamps(int B, int side, int D) {
+  Bufs b = make(B, side, D, false);
+  CK(hipMemset(b.ls, 0, D * 4));
+  const int maxwg = 4096;
+  unsigned long long* dbuf; CK(hipMalloc(&dbuf, maxwg * 4 * 8));
+  std::vector<unsigned long long> h(maxwg * 4);
+  printf("stamps B=%d: mean shader-clock cycles per workgroup (100 MHz s_memtime ticks x clock ratio not applied: raw s_memtime units)\n", B);
+  for (int var = 0; var < NVAR; ++var)
+    for (const Case& c : CASES) {
+      GemmArgs g = args_for(b, c);
+      if (!vit_gemm256_fits(c.e, g)) continue;
+      const int nwg = ceil_div(g.M, 256) * (g.N / 256);
+      for (int i = 0; i < 3; ++i) CK(launch_vit_gemm256_variant(var, OP_F16, c.e, g, 0));
+      CK(hipMemset(dbuf, 0, maxwg * 4 * 8));
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g256_stamps), &dbuf, sizeof(dbuf)));
+      CK(launch_vit_gemm256_variant(var, OP_F16, c.e, g, 0));
+      CK(hipDeviceSynchronize());
+      unsigned long long* nul = nullptr;
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g256_stamps), &nul, sizeof(nul)));
+      CK(hipMemcpy(h.data(), dbuf, (size_t)nwg * 4 * 8, hipMemcpyDeviceToHost));
+      double pro = 0, mainl = 0, epi = 0; unsigned long long first = ~0ull, last = 0;
+      for (int w = 0; w < nwg; ++w) {
+        pro += (double)(h[4 * w + 1] - h[4 * w]); mainl += (double)(h[4 * w + 2] - h[4 * w + 1]); epi += (double)(h[4 * w + 3] - h[4 * w + 2]);
+        first = std::min(first, h[4 * w]); last = std::max(last, h[4 * w + 3]);
+      }
+      printf("  schedule %d %s %4d WGs: prologue %8.0f  main loop %8.0f (%2d K-tiles: %6.0f per K-tile)  epilogue %8.0f  | kernel span %8llu\n", var,
+             c.name, nwg, pro / nwg, mainl / nwg, g.K / 64, mainl / nwg / (g.K / 64), epi / nwg, last - first);
+    }
+  CK(hipFree(dbuf));
+  release(b);
+}
+
+int main(int argc, char** argv) {
+  const std::string mode = argc > 1 ? argv[1] : "both";
+  std::vector<int> Bs;
+  for (int i = 2; i < argc; ++i) Bs.push_back(atoi(argv[i]));
+  if (Bs.empty()) Bs = {64};
+  int bad = 0;
+  if (mode == "check" || mode == "both") {
+    printf("check (224^2, 16 x 16 patches)\n");
+    bad += check(64, 16, 768, false);
+    bad += check(16, 16, 768, true);      // ragged last tile: 4224 rows = 16.5 tiles
+    bad += check(33, 16, 1024, false);    // ViT-L widths, 8712 rows
+    printf("check (518^2, 37 x 37 patches)\n");
+    bad += check(8, 37, 768, false);
+    printf(bad ? "CHECK FAILED\n" : "CHECK OK\n");
+  }
+  if (mode == "stamps")
+    for (int B : Bs) stamps(B, 16, 768);
+  if (mode == "time" || mode == "both")
+    for (int B : Bs) time_all(B, 16, 768);
+  return bad ? 1 : 0;
+}

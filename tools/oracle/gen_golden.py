@@ -268,11 +268,9 @@ def gen_e2e(ref):
     save("e2e", **arrs)
 
 
-def gen_vit_hf():
-    """Second opinion on the ViT restatement: the independent HF port, random weights mapped from ours."""
+def _hf_dinov2(w, depth):
+    """transformers.Dinov2WithRegistersModel (the independent port) carrying OUR state dict ``w``."""
     from transformers import Dinov2WithRegistersConfig, Dinov2WithRegistersModel
-    depth = 2
-    w = W.synth_dinov2(81, depth=depth)
     cfg = Dinov2WithRegistersConfig(hidden_size=768, num_hidden_layers=depth, num_attention_heads=12, mlp_ratio=4,
                                     image_size=518, patch_size=14, num_register_tokens=4, layerscale_value=1.0,
                                     hidden_act="gelu", qkv_bias=True, use_swiglu_ffn=False, layer_norm_eps=1e-6,
@@ -303,17 +301,44 @@ def gen_vit_hf():
     sd["layernorm.weight"], sd["layernorm.bias"] = w["norm.weight"], w["norm.bias"]
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not missing and not unexpected, (missing, unexpected)
+    return m
+
+
+def _hf_forward(m, imgs):
+    try:
+        return m(pixel_values=imgs, interpolate_pos_encoding=True).last_hidden_state
+    except TypeError:
+        return m(pixel_values=imgs).last_hidden_state
+
+
+def gen_vit_hf():
+    """Second opinion on the ViT restatement: the independent HF port, random weights mapped from ours."""
+    depth = 2
+    m = _hf_dinov2(W.synth_dinov2(81, depth=depth), depth)
     arrs = {}
     for size in (224, 518):
         imgs = W.synth_images(82, 2, size)
-        try:
-            out = m(pixel_values=imgs, interpolate_pos_encoding=True).last_hidden_state
-        except TypeError:
-            out = m(pixel_values=imgs).last_hidden_state
+        out = _hf_forward(m, imgs)
         arrs["out%d_cls" % size] = out[:, 0]
         arrs["out%d_reg" % size] = out[:, 1:5]
         arrs["out%d_patch_sample" % size] = out[:, 5::53]
     save("vit_hf_crosscheck", **arrs)
+
+
+def gen_vit_hf12():
+    """Full-depth (12 blocks) outputs of the independent HF port for the GPU tests (tests/test_gpu_vit_hf.py): plain
+    synthetic weights and the outlier-channel variant (weights.add_outlier_channels), 224^2 and 518^2."""
+    depth = 12
+    arrs = {}
+    for tag, w in (("plain", W.synth_dinov2(83, depth=depth)),
+                   ("outlier", W.add_outlier_channels(W.synth_dinov2(83, depth=depth)))):
+        m = _hf_dinov2(w, depth)
+        for size, stride in ((224, 7), (518, 29)):
+            out = _hf_forward(m, W.synth_images(84, 2, size))
+            arrs["%s%d_global" % (tag, size)] = out[:, :5]
+            arrs["%s%d_patch_sample" % (tag, size)] = out[:, 5::stride]
+            arrs["%s%d_absmax" % (tag, size)] = out.abs().max()
+    save("vit_hf_depth12", **arrs)
 
 
 def main():
@@ -334,6 +359,7 @@ def main():
     if want("pinv"): gen_pinv(ref)
     if want("e2e"): gen_e2e(ref)
     if want("vit_hf"): gen_vit_hf()
+    if want("vit_hf12"): gen_vit_hf12()
 
 
 if __name__ == "__main__":
