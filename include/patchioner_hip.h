@@ -229,6 +229,10 @@ int64_t pio_bank_rows(pio_handle h);
 /* Host-only (no GPU needed): the load-time position-grid interpolation of pio_finalize_weights
  * (DINOv2 interpolate_pos_encoding: bicubic, antialias, offset 0).  pos [1+grid*grid, dim] -> out [1+n*n, dim]. */
 int pio_host_interpolate_pos_embed(const float* pos, int32_t grid, int32_t dim, int32_t n, float* out);
+/* the same for the hub models WITHOUT registers (num_registers = 0): bicubic without antialias on the scale factor
+ * (n + offset) / grid, offset 0.1 (facebookresearch/dinov2 vision_transformer.py interpolate_pos_encoding, reached from
+ * P/src/model.py:342-343, 783). */
+int pio_host_interpolate_pos_embed_plain(const float* pos, int32_t grid, int32_t dim, int32_t n, double offset, float* out);
 
 /* Host-only: the Pillow resampling table pio_preprocess builds for output samples [first, first + count) of an axis
  * resized from in_size to out_size (bicubic; Resample.c precompute_coeffs + normalize_coeffs_8bpc).  kk must hold

@@ -39,8 +39,9 @@ class DinoV2Oracle:
 
     ``w`` is a state dict in the hub model's own naming (``cls_token``, ``pos_embed``,
     ``register_tokens``, ``patch_embed.proj.*``, ``blocks.{i}.{norm1,attn.qkv,attn.proj,ls1,norm2,
-    mlp.fc1,mlp.fc2,ls2}.*``, ``norm.*``).  Registers models: interpolate_antialias=True,
-    interpolate_offset=0.0 (hub ``_reg`` entry points).
+    mlp.fc1,mlp.fc2,ls2}.*``, ``norm.*``).  Position interpolation follows the hub entry points: ``_reg`` models
+    interpolate_antialias=True, interpolate_offset=0.0; the models without registers antialias=False, offset=0.1
+    (``scale_factor = (n + 0.1) / M``, the kludge of facebookresearch/dino issue 8).
     """
 
     def __init__(self, w: Dict[str, torch.Tensor], num_heads: int, patch_size: int = 14,
@@ -62,8 +63,13 @@ class DinoV2Oracle:
         if n_h * n_w == N and n_h == n_w:
             return pe
         cls_pe, patch_pe = pe[:, :1], pe[:, 1:]
-        patch_pe = F.interpolate(patch_pe.reshape(1, M, M, self.D).permute(0, 3, 1, 2),
-                                 size=(n_h, n_w), mode="bicubic", antialias=True)
+        grid = patch_pe.reshape(1, M, M, self.D).permute(0, 3, 1, 2)
+        if self.R > 0:
+            patch_pe = F.interpolate(grid, size=(n_h, n_w), mode="bicubic", antialias=True)
+        else:
+            patch_pe = F.interpolate(grid, scale_factor=(float(n_h + 0.1) / M, float(n_w + 0.1) / M), mode="bicubic",
+                                     antialias=False)
+            assert patch_pe.shape[-2:] == (n_h, n_w)
         patch_pe = patch_pe.permute(0, 2, 3, 1).reshape(1, n_h * n_w, self.D)
         return torch.cat([cls_pe, patch_pe], dim=1)
 

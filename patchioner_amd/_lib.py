@@ -75,6 +75,7 @@ SIGNATURES = {
     "pio_grid_side": (c_int32, [c_void_p]),
     "pio_bank_rows": (c_int64, [c_void_p]),
     "pio_host_interpolate_pos_embed": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "pio_host_interpolate_pos_embed_plain": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_double, c_void_p]),
     "pio_host_pil_ksize": (c_int32, [c_int32, c_int32]),
     "pio_host_pil_table": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
 }

@@ -217,7 +217,10 @@ int finalize_vit(pio_context* c) {
   if ((rc = need(c, "pos_embed", {1 + (int64_t)g * g, D}, &t))) return rc;
   {
     std::vector<float> pos((size_t)(1 + c->n2) * D);
-    interpolate_pos_embed(t->data.data(), g, D, c->n, pos.data());
+    // hub variants: *_reg models interpolate with antialias and offset 0, the models without registers without
+    // antialias and with the historical 0.1 offset (dinov2/hub/backbones.py)
+    if (R > 0) interpolate_pos_embed(t->data.data(), g, D, c->n, pos.data());
+    else interpolate_pos_embed_plain(t->data.data(), g, D, c->n, 0.1, pos.data());
     if ((rc = upload_f32(c, pos.data(), pos.size(), &c->pos))) return rc;
   }
   if ((rc = need(c, "norm.weight", {D}, &t))) return rc;
@@ -1063,6 +1066,12 @@ int64_t pio_bank_rows(pio_handle c) { return c ? c->bank_rows : 0; }
 int pio_host_interpolate_pos_embed(const float* pos, int32_t grid, int32_t dim, int32_t n, float* out) {
   if (!pos || !out || grid < 1 || dim < 1 || n < 1) return fail(PIO_ERR_INVALID_ARG, "pio_host_interpolate_pos_embed: bad argument");
   interpolate_pos_embed(pos, grid, dim, n, out);
+  return PIO_OK;
+}
+
+int pio_host_interpolate_pos_embed_plain(const float* pos, int32_t grid, int32_t dim, int32_t n, double offset, float* out) {
+  if (!pos || !out || grid < 1 || dim < 1 || n < 1) return fail(PIO_ERR_INVALID_ARG, "pio_host_interpolate_pos_embed_plain: bad argument");
+  interpolate_pos_embed_plain(pos, grid, dim, n, offset, out);
   return PIO_OK;
 }
 

@@ -106,4 +106,48 @@ inline void interpolate_pos_embed(const float* pos, int g, int D, int n, float* 
     }
 }
 
+// ---- torch.nn.functional.interpolate(mode="bicubic", antialias=False, scale_factor=(n + offset) / g) ----
+// What the hub builds the models WITHOUT registers with (interpolate_antialias=False, interpolate_offset=0.1): ATen's
+// upsample_bicubic2d, align_corners=False: source coordinate (o + 0.5) / scale_factor - 0.5 (the scale factor that was
+// GIVEN, not n / g), Keys cubic with a = -0.75, four taps with clamped indices; output size floor(g * scale) = n.
+inline void cubic_taps_m075(float t, float w[4]) {
+  const float A = -0.75f;
+  const float x0 = t + 1.0f, x3 = 2.0f - t, x2 = 1.0f - t;
+  w[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+  w[1] = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+  w[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+  w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+
+inline void interpolate_pos_embed_plain(const float* pos, int g, int D, int n, double offset, float* out) {
+  std::memcpy(out, pos, sizeof(float) * D);
+  if (n == g) {
+    std::memcpy(out + D, pos + D, sizeof(float) * (size_t)g * g * D);
+    return;
+  }
+  const float inv = (float)(1.0 / (((double)n + offset) / (double)g));     // ATen: static_cast<float>(1.0 / scale_factor)
+  std::vector<int> idx((size_t)n * 4);
+  std::vector<float> wt((size_t)n * 4);
+  for (int o = 0; o < n; ++o) {
+    const float real = inv * ((float)o + 0.5f) - 0.5f;
+    const float fl = std::floor(real);
+    cubic_taps_m075(real - fl, &wt[(size_t)o * 4]);
+    for (int k = 0; k < 4; ++k) idx[(size_t)o * 4 + k] = std::min(std::max((int)fl - 1 + k, 0), g - 1);
+  }
+  for (int oy = 0; oy < n; ++oy)
+    for (int ox = 0; ox < n; ++ox) {
+      float* dst = out + D + ((size_t)oy * n + ox) * D;
+      for (int d = 0; d < D; ++d) {
+        float acc = 0.f;
+        for (int j = 0; j < 4; ++j) {
+          const float* row = pos + D + (size_t)idx[(size_t)oy * 4 + j] * g * D + d;
+          float r = 0.f;
+          for (int i = 0; i < 4; ++i) r += wt[(size_t)ox * 4 + i] * row[(size_t)idx[(size_t)ox * 4 + i] * D];
+          acc += wt[(size_t)oy * 4 + j] * r;
+        }
+        dst[d] = acc;
+      }
+    }
+}
+
 }  // namespace pio

@@ -347,14 +347,20 @@ static hipError_t launch_typed(GemmEpilogue epi, const GemmArgs& a, hipStream_t 
   return hipErrorInvalidValue;
 }
 
-// rows from which the 256 x 256 kernel (vit_gemm256.hip) takes over; PIO_GEMM256_MIN_M overrides (0 = never)
-static int gemm256_min_m() {
-  static const int v = [] { const char* e = getenv("PIO_GEMM256_MIN_M"); return e ? atoi(e) : 8192; }();
+// The 256 x 256 kernel (vit_gemm256.hip) takes a GEMM over once it has enough 256-tiles to occupy the chip: measured
+// on MI355X (tools/microbench/gemm256_bench.hip, profiles/r02_gemm256_microbench_*.log) it wins from ~150 tiles on (qkv
+// and fc1 at 16 images: 153 / 204 tiles, 25.7 vs 27.8 and 30.4 vs 35.9 us; every GEMM at 64 images) and loses below
+// (proj / fc2 at 16 images: 51 tiles).  Same arithmetic per output element, so the choice never changes a result.
+// PIO_GEMM256_MIN_TILES overrides the threshold (0 = never use it).
+static int gemm256_min_tiles() {
+  static const int v = [] { const char* e = getenv("PIO_GEMM256_MIN_TILES"); return e ? atoi(e) : 144; }();
   return v;
 }
 
 hipError_t launch_vit_gemm(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
-  if (gemm256_min_m() > 0 && a.M >= gemm256_min_m() && vit_gemm256_fits(epi, a)) return launch_vit_gemm256(t, epi, a, s);
+  if (gemm256_min_tiles() > 0 && a.M > 0 && a.N % 256 == 0 && ceil_div(a.M, 256) * (a.N / 256) >= gemm256_min_tiles() &&
+      vit_gemm256_fits(epi, a))
+    return launch_vit_gemm256(t, epi, a, s);
   if (a.M <= 0 || a.N % BN != 0 || a.K % (2 * BK) != 0 || a.lda % 8 != 0) return hipErrorInvalidValue;
   // the staging offsets are 32-bit byte offsets from A and W
   if ((size_t)a.M * a.lda * 2 >= ((size_t)1 << 32) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;

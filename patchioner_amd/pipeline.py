@@ -124,6 +124,15 @@ class TraceCaptionPipeline:
         self._nstaged += 1
         m, stream = self.stage_models[k], self.stage_streams[k]
         eng = m.engine
+        # The caller's batches were produced on ITS stream (an asynchronous H2D copy, model.preprocess_images, ...): the
+        # stage stream must not read them before that work has run, and the caching allocator must not hand their blocks
+        # to the loader's next batch while the stage stream still reads them (the caller drops its reference right after).
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.eng.device))
+        stream.wait_event(ready)
+        for im, _ in held:
+            if im.is_cuda:
+                im.record_stream(stream)
         with torch.cuda.stream(stream):
             imgs = held[0][0] if len(held) == 1 else torch.cat([h[0] for h in held], dim=0)
             want_qkv = self.use_attention_tracing and any(h[1] is not None for h in held)
@@ -159,6 +168,7 @@ class TraceCaptionPipeline:
                     ev = torch.cuda.Event()
                     ev.record(st)
                     stream.wait_event(ev)
+                    emb.record_stream(stream)
             emb = g.pending[0][0] if len(g.pending) == 1 else torch.cat([p[0] for p in g.pending], dim=0)
             pre = eng.project(emb.contiguous(), normalize=m.normalize) if m.im_proj is not None else emb
             if m.embed_inversion:

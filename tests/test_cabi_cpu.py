@@ -43,6 +43,25 @@ def test_pos_embed_interpolation_matches_torch(lib, n, D):
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("n,D", [(16, 768), (8, 384), (37, 64), (20, 64), (45, 32)])
+def test_pos_embed_interpolation_without_registers_matches_torch(lib, n, D):
+    """Hub models WITHOUT registers: bicubic, no antialias, scale_factor (n + 0.1) / 37 (the published
+    DinoVisionTransformer.interpolate_pos_encoding with interpolate_offset = 0.1), down- and up-sampling."""
+    import ctypes
+    g = 37
+    pos = torch.randn(1 + g * g, D, generator=torch.Generator().manual_seed(100 + n))
+    out = torch.empty(1 + n * n, D)
+    assert lib.pio_host_interpolate_pos_embed_plain(pos.data_ptr(), g, D, n, ctypes.c_double(0.1), out.data_ptr()) == 0
+    if n == g:
+        ref = pos[1:].reshape(g * g, D)
+    else:
+        ref = torch.nn.functional.interpolate(pos[1:].reshape(1, g, g, D).permute(0, 3, 1, 2), mode="bicubic",
+                                              antialias=False, scale_factor=(float(n + 0.1) / g, float(n + 0.1) / g))
+        assert ref.shape[-2:] == (n, n)
+        ref = ref.permute(0, 2, 3, 1).reshape(n * n, D)
+    np.testing.assert_allclose(out.numpy(), torch.cat([pos[:1], ref], 0).numpy(), rtol=1e-5, atol=2e-5)   # N(0, 1) inputs, 16 products per output: FMA contraction differs from ATen
+
+
 def test_invalid_arguments_fail_loudly(lib):
     from patchioner_amd import _lib
     assert lib.pio_host_interpolate_pos_embed(None, 37, 8, 4, None) == -1

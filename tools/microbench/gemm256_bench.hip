@@ -97,21 +97,23 @@ static void reset_outputs(const Bufs& b) {
   fill32(b.x, b.sz_x / 4, 1.0f, 0.f, 9);
 }
 
-static const int NVAR = 2;
+static const int NVAR = 2;      // candidates beside the 128-tile kernel: 256 kernel schedule 0, schedule 1
+static hipError_t launch_candidate(int var, OperandType op, GemmEpilogue e, const GemmArgs& g) { return launch_vit_gemm256_variant(var, op, e, g, 0); }
+static bool candidate_fits(int, GemmEpilogue e, const GemmArgs& g) { return vit_gemm256_fits(e, g); }
 static int check(int B, int side, int D, bool bf) {
   Bufs b = make(B, side, D, bf);
   const OperandType op = bf ? OP_BF16 : OP_F16;
   int bad = 0;
   for (const Case& c : CASES) {
     GemmArgs g = args_for(b, c);
-    if (!vit_gemm256_fits(c.e, g)) { printf("  %s: shape not served by the 256 kernel\n", c.name); continue; }
+    if (!vit_gemm256_fits(c.e, g) ) { printf("  %s: shape not served by the new kernels\n", c.name); continue; }
     reset_outputs(b);
     CK(launch_vit_gemm(op, c.e, g, 0)); CK(hipDeviceSynchronize());
     const std::vector<uint8_t> ref = snapshot(b);
     size_t worst = 0;
     for (int rep = 0; rep < 2 * NVAR; ++rep) {       // repeated: a race would not reproduce identically
       reset_outputs(b);
-      CK(launch_vit_gemm256_variant(rep % NVAR, op, c.e, g, 0)); CK(hipDeviceSynchronize());
+      CK(launch_candidate(rep % NVAR, op, c.e, g)); CK(hipDeviceSynchronize());
       const std::vector<uint8_t> got = snapshot(b);
       size_t nd = 0, first = 0;
       for (size_t i = 0; i < ref.size(); ++i) if (ref[i] != got[i]) { if (!nd) first = i; ++nd; }
@@ -138,12 +140,11 @@ static void time_all(int B, int side, int D) {
   double tot[1 + NVAR] = {0, 0, 0}, totfl = 0;
   for (const Case& c : CASES) {
     GemmArgs g = args_for(b, c);
-    const bool fits = vit_gemm256_fits(c.e, g);
     std::vector<float> tt[1 + NVAR];
     for (int r = 0; r < rounds; ++r) {
       for (int which = 0; which < 1 + NVAR; ++which) {
-        if (which >= 1 && !fits) continue;
-        auto go = [&]() { return which ? launch_vit_gemm256_variant(which - 1, OP_F16, c.e, g, 0) : launch_vit_gemm(OP_F16, c.e, g, 0); };
+        if (which >= 1 && !candidate_fits(which - 1, c.e, g)) continue;
+        auto go = [&]() { return which ? launch_candidate(which - 1, OP_F16, c.e, g) : launch_vit_gemm(OP_F16, c.e, g, 0); };
         for (int i = 0; i < 2; ++i) CK(go());
         CK(hipEventRecord(e0, 0));
         for (int i = 0; i < it; ++i) CK(go());
@@ -205,6 +206,7 @@ static void stamps(int B, int side, int D) {
 }
 
 int main(int argc, char** argv) {
+  setenv("PIO_GEMM256_MIN_TILES", "0", 1);     // launch_vit_gemm stays the 128-tile kernel here: it is the reference column
   const std::string mode = argc > 1 ? argv[1] : "both";
   std::vector<int> Bs;
   for (int i = 2; i < argc; ++i) Bs.push_back(atoi(argv[i]));
