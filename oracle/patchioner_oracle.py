@@ -460,6 +460,7 @@ class PatchionerOracle:
         self.num_attn_heads, self.scale = num_attn_heads, scale
         self.A_pinv, self.b = A_pinv, b
         self.last_ids = None
+        self.call_log = None            # tests: a list collects the greedy ids of every caption_tokens call
 
     def caption_tokens(self, tokens, project_flag=True, compute_scores=False):
         if self.bank is None:
@@ -469,6 +470,8 @@ class PatchionerOracle:
             x = revert_transformation(x, self.A_pinv, self.b)
         ids, lps, _ = self.decoder.decode_ids(x)
         self.last_ids = ids
+        if self.call_log is not None:
+            self.call_log.append(ids.clone())
         caps = ids_to_captions(ids.tolist(), self.decode_fn)
         if compute_scores:
             return caps, torch.exp(lps.sum(-1)).tolist()

@@ -192,6 +192,7 @@ class Patchioner(nn.Module):
             self.im_proj = None
         self.tokenizer = ClipDetokenizer()
         self.last_ids = None
+        self.call_log = None            # tests: a list collects (decoder prefix, greedy ids) of every caption_tokens call
         self._defer = False
         self.dino = self.engine     # callers test `model.dino is not None`
         # one zero-size parameter so `next(model.parameters()).device` works as in the reference
@@ -529,6 +530,8 @@ class Patchioner(nn.Module):
             prefix = eng.revert_transformation(prefix)
         ids, lp = eng.decode_greedy(prefix, steps=30, want_logprob=compute_scores)
         self.last_ids = ids
+        if self.call_log is not None:
+            self.call_log.append((prefix.detach().clone(), ids.detach().clone()))
         if self._defer:
             if compute_scores:
                 raise NotImplementedError("forward_async does not defer score lists; call forward() for compute_scores")

@@ -1,0 +1,45 @@
+"""How the GPU tests compare captions that went THROUGH the fp16 / bf16 backbone with fp32 references.
+
+north_star: "greedy-decode token ids bit-exact".  The decoder stage is exactly that: on identical prefixes the HIP
+decoder's ids equal the oracle's, always (asserted below for every prefix of every call).  Through the backbone the
+prefix itself differs from the fp32 path's by the stated ViT tolerance, and an arg-max can only follow the reference
+while its top-2 logit margin exceeds what that perturbation moves the logits by.  So a caption is accepted iff
+
+  (1) the HIP ids equal the oracle decoder's ids on the HIP path's OWN prefix, bit for bit, and
+  (2) either they also equal the reference ids, or at the FIRST step where they depart from the reference (identical
+      history up to there) the oracle's top-2 logit margin on that prefix is at most MARGIN_BOUND.
+
+No test accepts a fraction of wrong captions: every departure has to be explained by (2), one by one.
+MARGIN_BOUND = 0.05 logit units against logits spanning about +-4 (fixtures' median top-2 margin: 0.5): the projection
+softmax at temperature 0.01 multiplies the backbone's 6e-4 relative token error by up to 100 before it reaches the
+decoder prefix, and the largest margin ever observed at a departure is printed by every test (round 2: see DESIGN.md).
+"""
+import torch
+
+MARGIN_BOUND = 0.05
+
+
+def assert_ids_explained(dec_oracle, gpu_log, ref_ids, label=""):
+    """gpu_log: Patchioner.call_log entries (prefix [n, E] cuda, ids [n, 30] cuda); ref_ids: list of [n_i, 30] integer
+    arrays / tensors in the same row order (the reference's or the oracle's ids through the fp32 backbone).
+    Returns (identical captions, total)."""
+    P = torch.cat([p for p, _ in gpu_log]).float().cpu()
+    G = torch.cat([i for _, i in gpu_log]).cpu().long()
+    R = torch.cat([torch.as_tensor(r).long().reshape(-1, G.shape[1]) for r in ref_ids])
+    assert G.shape == R.shape, (label, G.shape, R.shape)
+    keep = torch.isfinite(P).all(dim=1)          # NaN prefixes (dummy boxes): the reference decodes garbage from NaN as well
+    o_ids, _, o_margin = dec_oracle.decode_ids(P[keep])
+    assert torch.equal(G[keep], o_ids), "%s: decoder ids differ from the oracle on identical prefixes" % label
+    Gk, Rk = G[keep], R[keep]
+    worst, departed = 0.0, 0
+    for r in (Gk != Rk).any(dim=1).nonzero().flatten().tolist():
+        t = int((Gk[r] != Rk[r]).nonzero()[0])
+        m = float(o_margin[r, t])
+        worst = max(worst, m)
+        departed += 1
+        assert m <= MARGIN_BOUND, ("%s: caption %d departs from the reference at step %d where the top-2 margin is %.3e "
+                                   "(> %.2e): not a near-tie" % (label, r, t, m, MARGIN_BOUND))
+    total = int(keep.sum())
+    print("%s: %d / %d captions identical to the reference; %d departures, largest top-2 margin at a departure %.2e"
+          % (label, total - departed, total, departed, worst))
+    return total - departed, total

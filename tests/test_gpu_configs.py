@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import golden_cases as gc
+from parity_helpers import assert_ids_explained
 from patchioner_amd import weights as W
 
 pytestmark = pytest.mark.gpu
@@ -38,8 +39,8 @@ def _oracle_for(O, crop, with_bank, depth=2):
 
 def test_config3_518_boxes_16_regions(O):
     """talk2dino_decap at 518^2 (T = 1374), 16 gaussian-weighted boxes per image: box features against the
-    oracle on the GPU's own tokens (fp32 tolerance) and the captions of the whole path against the oracle
-    (>= 90 % identical: the backbone is fp16)."""
+    oracle on the GPU's own tokens (fp32 tolerance) and the token ids of the whole path against the oracle's
+    (parity_helpers: identical, or departing at a near-tie of the top-2 logits only)."""
     B, NB, crop = 2, 16, 518
     m = _model(crop, True, max_batch=2)
     orc = _oracle_for(O, crop, True)
@@ -54,13 +55,12 @@ def test_config3_518_boxes_16_regions(O):
     ref = O.extract_bboxes_feats(tokens[:, 5:].cpu(), boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=1.0)
     np.testing.assert_allclose(feats.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-6)
 
+    m.call_log, orc.call_log = [], []
     got = m(imgs.cuda(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=1.0)
     want = orc.forward(imgs.clone(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=1.0)
     assert len(got["bbox_capts"]) == B and all(len(r) == NB for r in got["bbox_capts"])
-    flat_g, flat_w = sum(got["bbox_capts"], []), sum(want["bbox_capts"], [])
-    same = sum(a == b for a, b in zip(flat_g, flat_w))
-    print("config3: %d / %d box captions identical to the oracle" % (same, len(flat_w)))
-    assert same >= 0.9 * len(flat_w)
+    _, total = assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "config3 (518^2, 16 boxes)")
+    assert total == B * NB
 
 
 def test_config4_capdec_dense_boxes_chunked(O):
@@ -76,13 +76,11 @@ def test_config4_capdec_dense_boxes_chunked(O):
     b = np.concatenate([xy, wh], -1).astype(np.float32)
     b[:, -3:] = [0.0, 0.0, 1.0, 1.0]                       # padding boxes of the dense-captioning driver
     boxes = torch.tensor(b)
+    m.call_log, orc.call_log = [], []
     got = m(imgs.cuda(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=0.5)
     want = orc.forward(imgs.clone(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=0.5)
-    flat_g, flat_w = sum(got["bbox_capts"], []), sum(want["bbox_capts"], [])
-    assert len(flat_g) == B * NB
-    same = sum(a == c for a, c in zip(flat_g, flat_w))
-    print("config4: %d / %d box captions identical to the oracle" % (same, len(flat_w)))
-    assert same >= 0.9 * len(flat_w)
+    assert len(sum(got["bbox_capts"], [])) == len(sum(want["bbox_capts"], [])) == B * NB
+    assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "config4 (CapDec, dense boxes)")
     # decoder stage alone on identical prefixes: bit-exact ids for all 144 prefixes
     tokens, _ = m.engine.vit_forward(imgs)
     feats = m._bbox_feats(tokens, boxes.clone(), True, 0.5, False, None).view(-1, 768)
@@ -127,17 +125,14 @@ def test_nested_caption_outputs_heads_patches_registers(O):
     orc = _oracle_for(O, crop, True)
     imgs = W.synth_images(12, B, crop)
     kw = dict(get_cls_capt=False, get_attn_heads_capt=True, get_patch_capts=True, get_register_capts=True)
+    m.call_log, orc.call_log = [], []
     got = m(imgs.cuda(), **kw)
     want = orc.forward(imgs.clone(), **kw)
     assert set(got) == set(want) == {"attn_heads_capts", "patch_tokens_capts", "register_capts"}
-    total = same = 0
     for key, per in (("attn_heads_capts", 16), ("patch_tokens_capts", 256), ("register_capts", 4)):
         assert len(got[key]) == B and all(len(r) == per for r in got[key])
-        for a, b in zip(sum(got[key], []), sum(want[key], [])):
-            total += 1
-            same += a == b
-    print("nested outputs: %d / %d captions identical to the oracle" % (same, total))
-    assert same >= 0.9 * total
+    _, total = assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "nested outputs (heads, patches, registers)")
+    assert total == B * (16 + 256 + 4)
 
 
 def test_grouped_decode_pipeline_matches_synchronous_forward():
@@ -255,11 +250,11 @@ def test_vits14_backbone_readout_and_captions(O, golden):
     assert err <= 4e-3
     orc = O.PatchionerOracle(vit, O.DeCapOracle(dec), bank, ClipDetokenizer().decode, crop_dim=224, num_attn_heads=6)
     kw = dict(get_cls_capt=True, get_avg_self_attn_capt=True, traces=[gc.block_trace(3, 4), gc.block_trace(9, 2), gc.block_trace(0, 12)])
+    m.call_log, orc.call_log = [], []
     got, want = m(imgs.cuda(), **kw), orc.forward(imgs.clone(), **kw)
-    same = sum(a == b for k in want for a, b in zip(got[k], want[k]))
-    total = sum(len(want[k]) for k in want)
-    print("vit-S captions: %d / %d identical to the oracle" % (same, total))
-    assert set(got) == set(want) and same >= total - 1
+    assert set(got) == set(want)
+    _, total = assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "ViT-S/14 DeCap path")
+    assert total == 9
 
 
 def test_ctx_cleaner_kernel_and_forward(O, golden):
@@ -287,13 +282,12 @@ def test_ctx_cleaner_kernel_and_forward(O, golden):
     for ct, after, cf in (("orthogonal_projection", True, "cls"), ("contrastive_mask", False, "avg_self_attn")):
         kw = dict(get_cls_capt=True, bboxes=None, cleaning_type=ct, clean_after_projection=after, alpha=0.8, clean_from=cf,
                   gaussian_avg=True, gaussian_bbox_variance=0.5)
+        m.call_log, orc.call_log = [], []
         got = m(imgs.cuda(), **{**kw, "bboxes": boxes.clone()})
         want = orc.forward(imgs.clone(), **{**kw, "bboxes": boxes.clone()})
-        flat_g = got["cls_capt"] + sum(got["bbox_capts"], [])
-        flat_w = want["cls_capt"] + sum(want["bbox_capts"], [])
-        same = sum(a == b for a, b in zip(flat_g, flat_w))
-        print("cleaning %s after=%s from=%s: %d / %d captions identical to the oracle" % (ct, after, cf, same, len(flat_w)))
-        assert len(flat_g) == len(flat_w) == 10 and same >= 9
+        assert len(got["cls_capt"] + sum(got["bbox_capts"], [])) == len(want["cls_capt"] + sum(want["bbox_capts"], [])) == 10
+        _, total = assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "cleaning %s after=%s from=%s" % (ct, after, cf))
+        assert total == 10
 
 
 def test_pipeline_soak_is_deterministic():
@@ -318,3 +312,28 @@ def test_pipeline_soak_is_deterministic():
             else:
                 assert torch.equal(ids, first), "group %d differs" % groups
     assert groups == 75
+
+
+def test_pipeline_reads_batches_produced_on_the_callers_stream_and_freed_at_once():
+    """Batches that are still being produced on the caller's stream when they are handed over (asynchronous H2D copy
+    plus a kernel), dropped by the caller right after, and whose memory block the caching allocator hands to a tensor
+    that is immediately overwritten with NaN: the stage stream must wait for the producer and keep the block alive
+    (TraceCaptionPipeline._stage: event wait + record_stream)."""
+    from patchioner_amd.pipeline import TraceCaptionPipeline
+    m = _model(224, True, max_batch=16)
+    host = [W.synth_images(200 + i, 8, 224).pin_memory() for i in range(12)]
+    traces = [gc.block_trace(i % 13, (5 * i) % 13) for i in range(8)]
+    want = [m(h.cuda(), get_cls_capt=False, traces=traces)["trace_capts"] for h in host]
+
+    def produce():
+        for h in host:
+            x = h.to("cuda", non_blocking=True) * 1.0
+            yield x, traces
+            del x
+            junk = torch.empty(8, 3, 224, 224, device="cuda")       # same size: the allocator's first choice is x's block
+            junk.fill_(float("nan"))
+            del junk
+
+    for vb in (1, 2):
+        got = list(TraceCaptionPipeline(m, group_batches=4, vit_batches=vb).run(produce()))
+        assert got == want, "vit_batches=%d" % vb

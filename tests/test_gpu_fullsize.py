@@ -84,3 +84,99 @@ def test_pipeline_equals_synchronous_forward_at_full_size(full):
     want = [m(b, get_cls_capt=False, traces=t)["trace_capts"] for b, t in batches]
     got = list(TraceCaptionPipeline(m, group_batches=8).run(batches))
     assert got == want
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs 2 (dense variant), 3 and 4 at FULL size: full-depth backbone, full bank, the configs' own batch shapes
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def O():
+    from oracle import patchioner_oracle
+    return patchioner_oracle
+
+
+def _stagewise_checks(O, m, bank_cpu, imgs, boxes, variance, label):
+    """One forward with gaussian-weighted boxes, every stage AFTER the backbone held to the oracle on the HIP path's own
+    inputs of that stage: box features (fp32 tolerance), projection (fp32 tolerance, the full bank), greedy ids (bit-exact)."""
+    B, NB = boxes.shape[:2]
+    tokens, _ = m.engine.vit_forward(imgs)
+    assert torch.isfinite(tokens).all()
+    feats = m._bbox_feats(tokens, boxes.clone(), True, variance, False, None)
+    ref = O.extract_bboxes_feats(tokens[:, m.num_global_tokens:].cpu(), boxes.clone(), gaussian_avg=True,
+                                 gaussian_bbox_variance=variance)
+    np.testing.assert_allclose(feats.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-6)
+    m.call_log = []
+    out = m(imgs, get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=variance)
+    assert len(out["bbox_capts"]) == B and all(len(r) == NB and all(isinstance(s, str) for s in r) for r in out["bbox_capts"])
+    prefix = torch.cat([p for p, _ in m.call_log]).cpu()
+    ids = torch.cat([i for _, i in m.call_log]).cpu().long()
+    m.call_log = None
+    assert prefix.shape[0] == B * NB
+    if bank_cpu is not None:
+        sub = slice(0, 16)                                   # one bank pass of the oracle: 3 x 1.8 GB on the host
+        want = O.project(feats.view(-1, feats.shape[-1])[sub].cpu().clone(), bank_cpu, normalize=True)
+        np.testing.assert_allclose(prefix[sub].numpy(), want.numpy(), rtol=2e-4, atol=5e-6)
+    ref_ids, _, margin = O.DeCapOracle(W.synth_decap(3)).decode_ids(prefix)
+    assert torch.equal(ids, ref_ids), "%s: ids differ from the oracle on identical prefixes (min margin %.2e)" % (label, float(margin.min()))
+    return out
+
+
+def test_config2_dense_variant_full_size(full, O):
+    """SURVEY 8d C2, dense variant: bboxes [16, 1, 4] = [14 cx, 14 cy, 42, 42], gaussian_avg, variance 1.0."""
+    m, bank, imgs, _ = full
+    rng = np.random.RandomState(2)
+    c = rng.randint(0, 13, size=(16, 2))
+    boxes = torch.tensor(np.concatenate([14.0 * c, np.full((16, 2), 42.0)], 1)[:, None, :], dtype=torch.float32)
+    out = _stagewise_checks(O, m, bank.cpu(), imgs, boxes, 1.0, "config 2 dense")
+    perm = torch.randperm(16, generator=torch.Generator().manual_seed(5)).tolist()
+    again = m(imgs[perm].contiguous(), get_cls_capt=False, bboxes=boxes[perm].clone(), gaussian_avg=True, gaussian_bbox_variance=1.0)
+    assert again["bbox_capts"] == [out["bbox_capts"][p] for p in perm]
+
+
+def test_config3_full_size_518_batch8_16_regions(full, O):
+    """talk2dino_decap at 518^2 (37 x 37 grid, T = 1374), batch 8, 16 gaussian boxes per image = 128 captions, 12 blocks,
+    the full bank."""
+    from patchioner_amd import Patchioner
+    _, bank, _, _ = full
+    cfg = {"decap_weights": W.synth_decap(3), "dino_weights": W.synth_dinov2(1), "memory_bank": bank, "prefix_size": 768,
+           "linear_talk2dino": False, "support_memory_size": M_FULL, "dino_model": "dinov2_vitb14_reg", "normalize": True,
+           "resize_dim": 518, "crop_dim": 518, "max_batch": 8, "max_prefixes": 128}
+    m = Patchioner.from_config(cfg, device="cuda")
+    imgs = W.synth_images(3, 8, 518).cuda()
+    rng = np.random.RandomState(13)
+    xy = rng.randint(0, 30, size=(8, 16, 2)) * 14.0
+    wh = rng.randint(1, 8, size=(8, 16, 2)) * 14.0 + rng.randint(0, 14, size=(8, 16, 2))
+    boxes = torch.tensor(np.concatenate([xy, wh], -1), dtype=torch.float32)
+    out = _stagewise_checks(O, m, bank.cpu(), imgs, boxes, 1.0, "config 3")
+    half = m(imgs[4:].contiguous(), get_cls_capt=False, bboxes=boxes[4:].clone(), gaussian_avg=True, gaussian_bbox_variance=1.0)
+    assert half["bbox_capts"] == out["bbox_capts"][4:]          # batch composition does not change a caption
+    m.engine.close()
+
+
+def test_config4_per_gpu_shard_full_size(O):
+    """talk2dino_capdec (no bank: raw region features into the decoder), one GPU's shard of the 64-image batch = 8 images
+    x 8 dense boxes, 12 blocks: the whole path against the oracle's ids through its fp32 backbone (parity_helpers bar)."""
+    from parity_helpers import assert_ids_explained
+    from patchioner_amd import Patchioner
+    from patchioner_amd.tokenizer import ClipDetokenizer
+    vit_sd, dec_sd = W.synth_dinov2(1), W.synth_decap(3)
+    cfg = {"decap_weights": dec_sd, "dino_weights": vit_sd, "memory_bank": None, "prefix_size": 768, "linear_talk2dino": False,
+           "support_memory_size": 0, "dino_model": "dinov2_vitb14_reg", "normalize": True, "resize_dim": 224, "crop_dim": 224,
+           "max_batch": 8, "max_prefixes": 64}
+    m = Patchioner.from_config(cfg, device="cuda")
+    dec = O.DeCapOracle(dec_sd)
+    orc = O.PatchionerOracle(O.DinoV2Oracle(vit_sd, num_heads=12), dec, None, ClipDetokenizer().decode, crop_dim=224)
+    imgs = W.synth_images(4, 8, 224)
+    rng = np.random.RandomState(4)
+    xy = rng.randint(0, 12, size=(8, 8, 2)) * 14.0
+    wh = rng.randint(1, 9, size=(8, 8, 2)) * 14.0
+    b = np.concatenate([xy, wh], -1).astype(np.float32)
+    b[:, -1] = [0.0, 0.0, 1.0, 1.0]                       # the dense-captioning driver's padding box
+    boxes = torch.tensor(b)
+    _stagewise_checks(O, m, None, imgs.cuda(), boxes, 0.5, "config 4")
+    m.call_log, orc.call_log = [], []
+    got = m(imgs.cuda(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=0.5)
+    want = orc.forward(imgs.clone(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=0.5)
+    assert [len(r) for r in got["bbox_capts"]] == [len(r) for r in want["bbox_capts"]] == [8] * 8
+    assert_ids_explained(dec, m.call_log, orc.call_log, "config 4 shard (8 x 8 boxes, CapDec, depth 12)")
+    m.engine.close()
