@@ -168,6 +168,12 @@ int pio_gaussian_map(pio_handle h, float variance, float* map_dev, pio_stream st
 int pio_mem_project(pio_handle h, float* q_dev, int32_t N, float temperature, int32_t normalize,
                     float* out_dev, int32_t n_best, float* best_sims_dev, pio_stream stream);
 
+/* Im2TxtProjector.project(..., return_argmax_text=True, return_n_best_sims=k) (P/src/decap/im2txtprojection/
+ * im2txtprojection.py:367-375): q [N, D] is L2-normalised IN PLACE (line 368), then for every query the k largest cosine
+ * similarities against the bank rows, descending (best_sims [N, k]), and the rows they belong to (best_rows [N, k], int64;
+ * ties: the lower row, like torch.argmax; row indices count the rows KEPT at load, as the reference's do).  1 <= k <= 16. */
+int pio_mem_topk(pio_handle h, float* q, int32_t N, int32_t k, float* best_sims, int64_t* best_rows, pio_stream stream);
+
 /* -- a10: (x - b) @ A_pinv^T (revert_transformation, P/src/embedding_utils.py:17-25). x_dev [N,D] ->
  *    out_dev [N,prefix_size]. */
 int pio_revert_transformation(pio_handle h, const float* x_dev, int32_t N, float* out_dev, pio_stream stream);

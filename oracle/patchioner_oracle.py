@@ -309,13 +309,26 @@ def compute_region_means(patch_embeddings: torch.Tensor, variance: float,
 # --------------------------------------------------------------------------------------------
 
 
+def load_bank_rows(embs: torch.Tensor) -> torch.Tensor:
+    """Im2TxtProjector.__init__ (im2txtprojection.py:343-345): rows of zero norm are dropped when the bank is loaded
+    (the caption texts are NOT filtered along: project(return_argmax_text=True) indexes the unfiltered list)."""
+    return embs[embs.norm(dim=-1) != 0]
+
+
 def project(image_embedding: torch.Tensor, bank: torch.Tensor, temperature: float = 0.01,
-            normalize: bool = False, return_n_best_sims: Optional[int] = None):
+            normalize: bool = False, return_n_best_sims: Optional[int] = None, return_argmax_text: bool = False,
+            text_dataset=None):
     """P/src/decap/im2txtprojection/im2txtprojection.py:353-385 (three passes over the bank; the
-    query is L2-normalised IN PLACE on the caller's tensor, line 368)."""
+    query is L2-normalised IN PLACE on the caller's tensor, line 368).  ``return_argmax_text`` (:371-375): the text of
+    the most similar row instead of the projected embedding."""
     bank_n = bank / bank.norm(dim=-1, keepdim=True)
     image_embedding /= image_embedding.norm(dim=-1, keepdim=True)
     sim = image_embedding @ bank_n.T.float()
+    if return_argmax_text:
+        argmax_texts = [text_dataset[int(idx)].decode() for idx in sim.argmax(dim=-1)]
+        if return_n_best_sims:
+            return argmax_texts, sim.sort(dim=-1, descending=True).values[:, :return_n_best_sims].tolist()
+        return argmax_texts
     sm = (sim / temperature).softmax(dim=-1)
     out = sm @ bank.float()
     if normalize:

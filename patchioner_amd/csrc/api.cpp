@@ -872,6 +872,16 @@ int pio_mem_project(pio_handle c, float* q, int32_t N, float temperature, int32_
   return PIO_OK;
 }
 
+int pio_mem_topk(pio_handle c, float* q, int32_t N, int32_t k, float* best_sims, int64_t* best_rows, pio_stream stream) {
+  if (!c || !q || !best_sims || !best_rows) return fail(PIO_ERR_INVALID_ARG, "pio_mem_topk: null argument");
+  if (!c->bank) return fail(PIO_ERR_NOT_READY, "pio_mem_topk: memory bank not set");
+  if (N < 1) return fail(PIO_ERR_INVALID_ARG, "pio_mem_topk: N < 1");
+  if (k < 1 || k > 16 || k > c->bank_rows) return fail(PIO_ERR_INVALID_ARG, "pio_mem_topk: k must be 1..16 and <= the rows of the bank");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  HIP_OK(launch_mem_topk(c->bank, c->bank_inv, c->bank_rows, c->bank_dim, q, N, k, c->sims, best_sims, best_rows, (hipStream_t)stream));
+  return PIO_OK;
+}
+
 int pio_revert_transformation(pio_handle c, const float* x, int32_t N, float* out, pio_stream stream) {
   if (!c || !x || !out || N < 1) return fail(PIO_ERR_INVALID_ARG, "pio_revert_transformation: bad argument");
   if (!c->has_inv) return fail(PIO_ERR_NOT_READY, "pio_revert_transformation: talk2dino.A_pinv / talk2dino.b not loaded");

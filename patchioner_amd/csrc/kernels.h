@@ -101,6 +101,9 @@ struct ProjectArgs {
   int parts; int n_best_cap;
 };
 hipError_t launch_mem_project(const ProjectArgs& a, hipStream_t s);
+// q normalised in place, then top-k cosine similarities and their rows per query (sims_scratch: [16][M] floats)
+hipError_t launch_mem_topk(const float* bank, const float* inv_norm, int64_t M, int D, float* q, int N, int k, float* sims_scratch,
+                           float* best_sims, int64_t* best_rows, hipStream_t s);
 hipError_t launch_row_inv_norm(const float* bank, int64_t M, int D, float* inv_norm, hipStream_t s);
 hipError_t launch_revert(const float* x, const float* b, const float* A_pinv, int N, int D, int P, float* out,
                          hipStream_t s);

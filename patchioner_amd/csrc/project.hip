@@ -310,7 +310,8 @@ __global__ __launch_bounds__(256) void k_project_sims(const float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void k_topk_desc(const float* __restrict__ sims, int64_t M, int k, float* out) {
+__global__ __launch_bounds__(256) void k_topk_desc(const float* __restrict__ sims, int64_t M, int k, float* out,
+                                                   long long* out_rows = nullptr) {
   // one workgroup per query; k rounds of block-wide arg-max with exclusion (k is tiny)
   __shared__ float s_v[4];
   __shared__ long long s_i[4];
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(256) void k_topk_desc(const float* __restrict__ sim
         if (s_i[w] >= 0 && (fi < 0 || s_v[w] > fv || (s_v[w] == fv && s_i[w] < fi))) { fv = s_v[w]; fi = s_i[w]; }
       taken[round] = fi;
       out[(size_t)n * k + round] = fv;
+      if (out_rows != nullptr) out_rows[(size_t)n * k + round] = fi;
     }
     __syncthreads();
   }
@@ -407,6 +409,20 @@ hipError_t launch_mem_project(const ProjectArgs& a, hipStream_t s) {
       hipLaunchKernelGGL(k_topk_desc, dim3(nq), dim3(256), 0, s, a.part_best, a.M, a.n_best,
                          a.best_sims + (size_t)q0 * a.n_best);
     }
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_mem_topk(const float* bank, const float* inv_norm, int64_t M, int D, float* q, int N, int k, float* sims_scratch,
+                           float* best_sims, int64_t* best_rows, hipStream_t s) {
+  if (N <= 0 || M <= 0 || k < 1 || k > 16 || (int64_t)k > M) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_l2norm_rows, dim3(N), dim3(256), 0, s, q, D);
+  for (int q0 = 0; q0 < N; q0 += PR_Q) {
+    const int nq = (N - q0) < PR_Q ? (N - q0) : PR_Q;
+    hipLaunchKernelGGL(k_project_sims, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, bank, inv_norm, M, D, q + (size_t)q0 * D, nq,
+                       sims_scratch);
+    hipLaunchKernelGGL(k_topk_desc, dim3(nq), dim3(256), 0, s, sims_scratch, M, k, best_sims + (size_t)q0 * k,
+                       (long long*)best_rows + (size_t)q0 * k);
   }
   return hipGetLastError();
 }

@@ -50,6 +50,7 @@ class Engine:
         self.max_batch, self.max_prefixes, self.max_steps = max_batch, max_prefixes, max_steps
         self.num_weights = 0
         self.bank_rows = 0
+        self.bank_dim = 0
         self._finalized = False
         self._stage_ring = [dict(host=None, dev=None, event=None) for _ in range(8)]
         self._stage_next = 0
@@ -94,11 +95,17 @@ class Engine:
     def set_memory_bank(self, bank: torch.Tensor) -> int:
         bank = bank.detach().to(torch.float32).contiguous()
         if bank.is_cuda:
+            # the reference drops zero-norm rows when it loads the bank (im2txtprojection.py:343-345); a zero row would
+            # give inv_norm = inf and NaN similarities
+            keep = bank.norm(dim=-1) != 0
+            if not bool(keep.all()):
+                bank = bank[keep].contiguous()
             check(self.lib.pio_set_memory_bank_device(self.h, ptr(bank), bank.shape[0], bank.shape[1]))
         else:
             kept = ctypes.c_int64(0)
             check(self.lib.pio_set_memory_bank(self.h, ptr(bank), bank.shape[0], bank.shape[1], ctypes.byref(kept)))
         self.bank_rows = int(self.lib.pio_bank_rows(self.h))
+        self.bank_dim = int(bank.shape[1])
         return self.bank_rows
 
     # ------------------------------------------------------------------ measurement
@@ -296,6 +303,8 @@ class Engine:
                 n_best: Optional[int] = None):
         """q [N,D] CUDA fp32 contiguous is L2-normalised IN PLACE (reference quirk)."""
         assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous()
+        if q.shape[1] != self.bank_dim:        # the kernel strides q / out by the bank's width
+            raise PioError(_lib.PIO_ERR_SHAPE, "query width %d does not match the %d-wide memory bank" % (q.shape[1], self.bank_dim))
         N = q.shape[0]
         out = torch.empty(N, q.shape[1], device=self.device, dtype=torch.float32)
         nb = int(n_best) if n_best else 0
@@ -303,6 +312,20 @@ class Engine:
         check(self.lib.pio_mem_project(self.h, ptr(q), N, float(temperature), 1 if normalize else 0, ptr(out), nb,
                                        ptr(best), _stream()))
         return (out, best) if nb else out
+
+    def topk_rows(self, q: torch.Tensor, k: int = 1):
+        """project(..., return_argmax_text=True, return_n_best_sims=k) without the texts: q [N, D] is L2-normalised IN PLACE,
+        returns (sims [N, k] descending, rows [N, k] int64) of the k most similar bank rows per query."""
+        assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous()
+        if q.shape[1] != self.bank_dim:
+            raise PioError(_lib.PIO_ERR_SHAPE, "query width %d does not match the %d-wide memory bank" % (q.shape[1], self.bank_dim))
+        N = q.shape[0]
+        sims = torch.empty(N, k, device=self.device, dtype=torch.float32)
+        rows = torch.empty(N, k, device=self.device, dtype=torch.int64)
+        for s in range(0, N, self.max_prefixes):
+            e = min(N, s + self.max_prefixes)
+            check(self.lib.pio_mem_topk(self.h, ptr(q[s:e]), e - s, int(k), ptr(sims[s:e]), ptr(rows[s:e]), _stream()))
+        return sims, rows
 
     def revert_transformation(self, x: torch.Tensor) -> torch.Tensor:
         x = self._dev(x)

@@ -29,7 +29,7 @@ import yaml
 
 from . import weights as W
 from .engine import Engine
-from .preprocess import make_transforms, process_bboxes
+from .preprocess import make_transforms
 from .tokenizer import ClipDetokenizer
 
 _OUT_OF_SCOPE = ("proxyclip_clipmodel", "viecap_config", "regionclip_config", "invite_config", "denseclip_config",
@@ -47,28 +47,32 @@ def _load_state_dict(spec):
     return sd.get("state_dict", sd) if isinstance(sd, dict) else sd
 
 
-def load_memory_bank(spec) -> torch.Tensor:
+def load_memory_bank(spec, want_texts: bool = False):
     """[M, D] fp32 text-embedding bank (Im2TxtProjector._load_support_memory,
-    P/src/decap/im2txtprojection/im2txtprojection.py:387-407: HDF5 dataset '<name>-embeddings')."""
+    P/src/decap/im2txtprojection/im2txtprojection.py:387-407: HDF5 datasets '<name>-embeddings' and '<name>-text',
+    read by the dependency-free h5lite).  ``want_texts``: returns (bank, list of bytes | None)."""
+    bank, texts = _load_memory_bank(spec)
+    return (bank, texts) if want_texts else bank
+
+
+def _load_memory_bank(spec):
     if isinstance(spec, torch.Tensor):
-        return spec.float()
+        return spec.float(), None
     if not os.path.exists(spec):
         raise FileNotFoundError("memory bank %r not found" % (spec,))
     if spec.endswith(".npy"):
         import numpy as np
-        return torch.from_numpy(np.load(spec)).float()
+        return torch.from_numpy(np.load(spec)).float(), None
     if spec.endswith(".pt") or spec.endswith(".pth"):
-        return torch.load(spec, map_location="cpu").float()
+        return torch.load(spec, map_location="cpu").float(), None
     if spec.endswith(".h5") or spec.endswith(".hdf5"):
-        try:
-            import h5py
-        except ImportError as e:  # pragma: no cover
-            raise ImportError("reading %r needs h5py (not installed); convert the bank to .npy" % spec) from e
-        with h5py.File(spec, "r") as hf:
-            names = [k for k in hf.keys() if k.endswith("-embeddings")]
-            if not names:
-                raise KeyError("no '<name>-embeddings' dataset in %r" % spec)
-            return torch.from_numpy(hf[names[0]][:]).float()
+        from . import h5lite
+        names = [k for k in h5lite.dataset_names(spec) if k.endswith("-embeddings")]
+        if not names:
+            raise KeyError("no '<name>-embeddings' dataset in %r" % spec)
+        tname = names[0][:-len("-embeddings")] + "-text"
+        d = h5lite.read_datasets(spec, names=(names[0], tname))
+        return torch.from_numpy(d[names[0]]).float(), d.get(tname)
     raise ValueError("unsupported memory bank format: %r" % (spec,))
 
 
@@ -81,7 +85,7 @@ class Patchioner(nn.Module):
                  use_open_clip=False, viecap_config=None, regionclip_config=None, invite_config=None,
                  denseclip_config=None, alphaclip_config=None, clipcap_config=None, hf_repo_id=None,
                  dino_weights=None, memory_bank=None, synthetic_seed=None, max_batch=16, max_prefixes=64,
-                 vit_dtype="fp16", **kwargs):
+                 vit_dtype="fp16", memory_bank_texts=None, **kwargs):
         super().__init__(**kwargs)
         given = dict(proxyclip_clipmodel=proxyclip_clipmodel, viecap_config=viecap_config,
                      regionclip_config=regionclip_config, invite_config=invite_config,
@@ -90,17 +94,17 @@ class Patchioner(nn.Module):
         for k in _OUT_OF_SCOPE:
             if given[k] is not None:
                 raise NotImplementedError("%s: backbone/head outside the MI355X hot-path scope (DINOv2 + DeCap/CapDec)" % k)
-        if use_open_clip or online_texts is not None or calculate_argmax_text:
-            raise NotImplementedError("use_open_clip / online_texts / calculate_argmax_text need the CLIP text tower "
-                                      "or the bank's caption texts: outside the hot-path scope")
+        if use_open_clip or online_texts is not None:
+            raise NotImplementedError("use_open_clip / online_texts need the CLIP text tower: outside the hot-path scope")
         if dino_model is None or 'dinov2' not in dino_model or 'dinotxt' in dino_model:
             raise ValueError("Unsupported backbone %r: this build implements the DINOv2 ViT-S/B/L-14 family" % (dino_model,))
-        if decoder_weights is None and synthetic_seed is None:
+        if decoder_weights is None and synthetic_seed is None and not calculate_argmax_text:
             raise ValueError("decap_weights is required (or synthetic_seed for seeded synthetic weights)")
         self.decoding_method = None
         self.viecap = None
         self.clipcap = None
-        self.calculate_argmax_text = False
+        self.calculate_argmax_text = bool(calculate_argmax_text)
+        self.text_dataset = memory_bank_texts
 
         # same validation order as the reference (P/src/model.py:144-162)
         if projection_type in ('coco', 'msmarco', 'blip', 'vg', 'vg-test') or support_memory_size == 0:
@@ -151,7 +155,7 @@ class Patchioner(nn.Module):
             vit_sd[bk] = torch.cat([bs[x] for x in attention_type], dim=0)
 
         dec_sd = _load_state_dict(decoder_weights)
-        if dec_sd is None:
+        if dec_sd is None and synthetic_seed is not None:
             dec_sd = W.synth_decap(synthetic_seed + 2, prefix_size)
 
         self.embed_inversion = talk2dino_weights is not None
@@ -171,14 +175,17 @@ class Patchioner(nn.Module):
                              max_batch=max_batch, max_prefixes=max_prefixes, vit_dtype=vit_dtype,
                              device_index=self._device.index, readout_heads=self.num_attn_heads, readout_scale=self.scale)
         self.engine.load_state_dict(vit_sd)
-        self.engine.load_state_dict(dec_sd)            # strict=False like the reference (decap.py:214)
+        if dec_sd is not None:                         # calculate_argmax_text without decoder weights: no decoder (model.py:165)
+            self.engine.load_state_dict(dec_sd)        # strict=False like the reference (decap.py:214)
         if inv_sd:
             self.engine.load_state_dict(inv_sd)
         self.engine.finalize()
 
         if support_memory_size > 0:
             if memory_bank is not None:
-                bank = load_memory_bank(memory_bank)
+                bank, texts = load_memory_bank(memory_bank, want_texts=True)
+                if self.text_dataset is None:
+                    self.text_dataset = texts
             elif synthetic_seed is not None:
                 bank = W.synth_bank(synthetic_seed + 3, support_memory_size, self.embed_dim)
             else:
@@ -186,10 +193,17 @@ class Patchioner(nn.Module):
                                         "bank (CLIP text tower + datasets) is offline work outside this scope")
             if 'dinov2' not in dino_model:      # normalize_memory_embs (P/src/model.py:174); never true here
                 bank = bank / bank.norm(dim=-1, keepdim=True)
+            if bank.dim() != 2 or bank.shape[1] != self.embed_dim:
+                raise ValueError("memory bank is %s, the %s backbone needs [M, %d]" % (tuple(bank.shape), dino_model, self.embed_dim))
             self.engine.set_memory_bank(bank)
             self.im_proj = self.engine
         else:
             self.im_proj = None
+        if self.calculate_argmax_text:
+            if self.im_proj is None or self.text_dataset is None:
+                raise ValueError("calculate_argmax_text needs the memory bank AND its caption texts (the '<name>-text' dataset of "
+                                 "the bank's .h5, or `memory_bank_texts`)")
+            self.text_dataset = [t if isinstance(t, bytes) else str(t).encode("utf-8") for t in self.text_dataset]
         self.tokenizer = ClipDetokenizer()
         self.last_ids = None
         self.call_log = None            # tests: a list collects (decoder prefix, greedy ids) of every caption_tokens call
@@ -238,6 +252,7 @@ class Patchioner(nn.Module):
             hf_repo_id=config.get('hf_repo_id', None),
             dino_weights=config.get('dino_weights', None),
             memory_bank=config.get('memory_bank', None),
+            memory_bank_texts=config.get('memory_bank_texts', None),
             synthetic_seed=config.get('synthetic_seed', None),
             max_batch=config.get('max_batch', 16),
             max_prefixes=config.get('max_prefixes', 64),
@@ -286,8 +301,10 @@ class Patchioner(nn.Module):
         if cleaning_type is not None and self.im_proj is None:
             # the reference calls self.im_proj.project unconditionally here (model.py:900-913)
             raise AttributeError("cleaning_type needs the memory-bank projector (support_memory_size > 0)")
-        if return_n_best_sims is not None:
-            raise NotImplementedError("return_n_best_sims is only usable with calculate_argmax_text in the reference")
+        if return_n_best_sims is not None and not self.calculate_argmax_text:
+            # caption_tokens returns the similarities only on the calculate_argmax_text path (model.py:1408-1411); without
+            # it the reference fails while unpacking (model.py:1030, 1036)
+            raise ValueError("return_n_best_sims needs a model built with calculate_argmax_text")
         if caption_bboxes_type is not None:
             return self.caption_bboxes(imgs, bboxes, caption_bboxes_type, compute_scores=compute_scores)
 
@@ -367,12 +384,15 @@ class Patchioner(nn.Module):
             # same captions / scores; the engine splits at its own capacities (16 queries per bank pass, max_prefixes
             # per decode), e.g. 128 boxes decode as 2 x 64 instead of 4 x 32 prefixes.
             del bbox_bs
-            ret = self.caption_tokens(bbox_feats, project=project_regions, compute_scores=compute_scores)
+            ret = self.caption_tokens(bbox_feats, project=project_regions, return_n_best_sims=return_n_best_sims,
+                                      compute_scores=compute_scores)
             if compute_scores is True:
-                outs['bbox_capts'], outs['bbox_scores'] = list(ret[0]), list(ret[1])
-            else:
-                outs['bbox_capts'] = list(ret)
-            outs['bbox_capts'] = [outs['bbox_capts'][i * n_boxes:(i + 1) * n_boxes] for i in range(bs)]
+                ret, scores = ret
+                outs['bbox_scores'] = list(scores)
+            if return_n_best_sims is not None:          # model.py:1023-1040: (captions, similarities) per chunk
+                ret, sims = ret
+                outs['bbox_sims'] = [list(sims)[i * n_boxes:(i + 1) * n_boxes] for i in range(bs)]
+            outs['bbox_capts'] = [list(ret)[i * n_boxes:(i + 1) * n_boxes] for i in range(bs)]
             if compute_scores is True:
                 outs['bbox_scores'] = [outs['bbox_scores'][i * n_boxes:(i + 1) * n_boxes] for i in range(bs)]
         elif bboxes is not None and get_controllable_capts:
@@ -492,11 +512,18 @@ class Patchioner(nn.Module):
         return self.engine.preprocess(images, self.resize_dim, self.crop_dim, no_crop=no_crop)
 
     def caption_bboxes(self, imgs, bboxes, capt_type='cls_capt', crop_boxes=False, compute_scores=False):
-        """P/src/model.py:1356-1390: crop each box from the PIL image and caption the crop."""
+        """P/src/model.py:1356-1390: crop each box from the PIL image, transform the crop (``image_transforms`` when
+        ``crop_boxes`` else ``image_transforms_no_crop``) and caption it with a whole forward pass, ``bs`` crops at a time.
+        process_bboxes (P/src/bbox_utils.py:406-421) runs the resampling on the host; here only PIL's crop (a copy of the
+        pixels, its float box rounded by PIL as in the reference) stays there and resize / centre-crop / normalisation run
+        on the GPU (pio_preprocess: the same floats as the PIL transform, tests/test_gpu_preprocess.py)."""
         bs = len(imgs)
         n_bboxes = bboxes.shape[1]
-        tf = self.image_transforms if crop_boxes else self.image_transforms_no_crop
-        crops = process_bboxes(imgs, bboxes, tf).to(self._device)
+        regions = []
+        for img, img_boxes in zip(imgs, bboxes.tolist()):
+            for x_min, y_min, w, h in img_boxes:
+                regions.append(img.crop((x_min, y_min, x_min + w, y_min + h)))
+        crops = self.preprocess_images(regions, no_crop=not crop_boxes)
         capts, scores = [], []
         for i in range(n_bboxes):
             start = i * bs
@@ -504,7 +531,7 @@ class Patchioner(nn.Module):
             out = self.forward(crops[start:end], get_cls_capt=capt_type == 'cls_capt',
                                get_avg_self_attn_capt=capt_type == 'avg_self_attn_capt')
             capts += out[capt_type]
-            if compute_scores:
+            if compute_scores:      # as in the reference: forward() is not asked for scores, so this key is missing (KeyError)
                 scores += out[f"{capt_type}_scores"]
         ret = {'bbox_capts': [capts[i * n_bboxes:(i + 1) * n_bboxes] for i in range(bs)]}
         if compute_scores:
@@ -520,6 +547,16 @@ class Patchioner(nn.Module):
         if not isinstance(x, torch.Tensor):
             x = torch.tensor(x, dtype=torch.float)
         xd = x.to(device=eng.device, dtype=torch.float32).contiguous()
+        if self.calculate_argmax_text:
+            # model.py:1408-1411 -> im2txtprojection.py:367-375: the text of the most similar bank row, no decoder.  The row
+            # index counts the rows kept at load while the texts are the file's unfiltered list (the reference's indexing).
+            sims, rows = eng.topk_rows(xd, k=int(return_n_best_sims) if return_n_best_sims else 1)
+            if isinstance(dino_tokens, torch.Tensor) and xd.data_ptr() != dino_tokens.data_ptr():
+                dino_tokens.copy_(xd)           # normalised in place (im2txtprojection.py:368)
+            captions = [self.text_dataset[int(r)].decode() for r in rows[:, 0].cpu().tolist()]
+            if return_n_best_sims:
+                captions = (captions, sims.cpu().tolist())
+            return captions if compute_scores is False else (captions, [1.0] * len(captions))   # the reference's len(): 2 for a (texts, sims) pair
         if project:
             prefix = eng.project(xd, normalize=self.normalize)
             if isinstance(dino_tokens, torch.Tensor) and xd.data_ptr() != dino_tokens.data_ptr():

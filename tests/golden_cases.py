@@ -191,3 +191,19 @@ CTX = dict(B=3, S=9, D=96, seed=31)
 def ctx_inputs():
     c = CTX
     return randn(c["seed"], c["B"], c["S"], c["D"]), randn(c["seed"] + 1, c["B"], c["D"])
+
+
+# ---- memory-bank file (HDF5 as the reference writes it) -----------------------------------------
+H5BANK = dict(name="coco", rows=40, dim=768, seed=77, zero_rows=(7, 23))
+
+
+def h5_bank_case():
+    """(embeddings [40, 768] float32 with two all-zero rows, 40 captions incl. non-ASCII and an empty one)."""
+    c = H5BANK
+    emb = randn(c["seed"], c["rows"], c["dim"]).numpy().astype(np.float32)
+    for r in c["zero_rows"]:
+        emb[r] = 0.0
+    words = ["a dog", "two cats on a sofa", "caf\u00e9 au lait", "\u5c71\u306e\u4e0a\u306e\u96ea", "a man riding a wave on top of a surfboard",
+             "", "na\u00efve r\u00e9sum\u00e9 \u2014 d\u00e9j\u00e0 vu", "x" * 300]
+    texts = ["%s #%d" % (words[i % len(words)], i) if words[i % len(words)] else "" for i in range(c["rows"])]
+    return emb, texts

@@ -337,3 +337,76 @@ def test_pipeline_reads_batches_produced_on_the_callers_stream_and_freed_at_once
     for vb in (1, 2):
         got = list(TraceCaptionPipeline(m, group_batches=4, vit_batches=vb).run(produce()))
         assert got == want, "vit_batches=%d" % vb
+
+
+def test_caption_bboxes_crop_and_recaption_vs_oracle(O):
+    """SURVEY 8f.2, Patchioner.caption_bboxes (P/src/model.py:1356-1390): every box cropped from its PIL image, transformed
+    (both crop_boxes modes) on the GPU and captioned by a whole forward pass (both capt_types), against the oracle fed with
+    the HOST transform of the same crops (process_bboxes, P/src/bbox_utils.py:406-421), chunk by chunk as the reference loops."""
+    from PIL import Image
+    from patchioner_amd.preprocess import process_bboxes
+    m = _model(224, True, max_batch=4)
+    orc = _oracle_for(O, 224, True)
+    rng = np.random.RandomState(21)
+    sizes = [(320, 240), (200, 333), (500, 375)]
+    imgs = [Image.fromarray(rng.randint(0, 256, size=(h, w, 3), dtype=np.uint8)) for w, h in sizes]
+    boxes = torch.tensor([[[10.0, 20.0, 150.0, 100.0], [0.0, 0.0, 320.0, 240.0], [100.5, 60.25, 80.0, 120.75], [300.0, 200.0, 60.0, 80.0]],
+                          [[5.0, 5.0, 100.0, 300.0], [50.0, 100.0, 140.0, 60.0], [0.0, 0.0, 30.0, 30.0], [150.0, 250.0, 50.0, 83.0]],
+                          [[0.0, 0.0, 499.0, 374.0], [250.0, 100.0, 200.0, 200.0], [20.0, 300.0, 460.0, 70.0], [400.0, 10.0, 150.0, 90.0]]])
+    for crop_boxes in (False, True):
+        tf = m.image_transforms if crop_boxes else m.image_transforms_no_crop
+        crops = process_bboxes(imgs, boxes, tf)
+        dev = m.preprocess_images([im.crop((x, y, x + w, y + h)) for im, bb in zip(imgs, boxes.tolist()) for x, y, w, h in bb],
+                                  no_crop=not crop_boxes)
+        assert torch.equal(dev.cpu(), crops), "device transform of the crops differs from the host transform"
+        for capt_type in ("cls_capt", "avg_self_attn_capt"):
+            m.call_log, orc.call_log = [], []
+            got = m.caption_bboxes(imgs, boxes.clone(), capt_type=capt_type, crop_boxes=crop_boxes)
+            bs, nb = len(imgs), boxes.shape[1]
+            want = []
+            for i in range(nb):                               # the reference's chunking: bs crops per forward
+                s, e = i * bs, (i * bs + bs if i < nb - 1 else crops.shape[0])
+                want += orc.forward(crops[s:e].clone(), get_cls_capt=capt_type == "cls_capt",
+                                    get_avg_self_attn_capt=capt_type == "avg_self_attn_capt")[capt_type]
+            assert set(got) == {"bbox_capts"} and [len(r) for r in got["bbox_capts"]] == [nb] * bs
+            _, total = assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "caption_bboxes crop=%s %s" % (crop_boxes, capt_type))
+            assert total == bs * nb
+    m.call_log = None
+    with pytest.raises(KeyError):                             # the reference never asks forward() for the scores it then reads
+        m.caption_bboxes(imgs, boxes.clone(), compute_scores=True)
+
+
+def test_argmax_text_and_n_best_sims_from_the_h5_bank(O):
+    """calculate_argmax_text (P/src/model.py:1408-1411 -> im2txtprojection.py:367-375): the bank and its caption texts come
+    from a real HDF5 file (tests/golden/bank_tiny.h5 through patchioner_amd/h5lite.py), the caption is the text of the most
+    similar row, return_n_best_sims adds the k largest cosines; box captions nest them as bbox_sims (model.py:1023-1041)."""
+    import os
+    from patchioner_amd import Patchioner
+    emb, texts = gc.h5_bank_case()
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bank_tiny.h5")
+    cfg = {"decap_weights": None, "prefix_size": 768, "linear_talk2dino": False, "support_memory_size": 40,
+           "dino_model": "dinov2_vitb14_reg", "normalize": True, "resize_dim": 224, "crop_dim": 224,
+           "dino_weights": W.synth_dinov2(91, depth=2), "memory_bank": path, "max_batch": 4, "calculate_argmax_text": True}
+    m = Patchioner.from_config(cfg, device="cuda")
+    assert m.engine.bank_rows == 38                                   # the two all-zero rows are dropped at load
+    bank = O.load_bank_rows(torch.from_numpy(emb))
+    tb = [t.encode() for t in texts]
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(21, 768, generator=g) * 0.1 + torch.from_numpy(emb[[1, 8, 9, 24, 39, 0, 17] * 3])
+    want_caps, want_sims = O.project(q.clone(), bank, return_argmax_text=True, return_n_best_sims=3, text_dataset=tb)
+    qd = q.cuda()
+    caps, sims = m.caption_tokens(qd, return_n_best_sims=3)
+    assert caps == want_caps
+    np.testing.assert_allclose(np.array(sims), np.array(want_sims), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(qd.cpu().numpy(), (q / q.norm(dim=-1, keepdim=True)).numpy(), rtol=1e-6, atol=1e-7)   # in place
+    assert m.caption_tokens(q.cuda()) == want_caps
+    assert m.caption_tokens(q.cuda(), compute_scores=True) == (want_caps, [1.0] * 21)
+    # through forward(): cls captions are bank texts; boxes carry bbox_sims
+    imgs = W.synth_images(3, 2, 224).cuda()
+    boxes = gc.e2e_boxes()[:2, :3]
+    out = m(imgs, get_cls_capt=True, bboxes=boxes.clone(), gaussian_avg=True, return_n_best_sims=2)
+    assert len(out["cls_capt"]) == 2 and all(c in texts for c in out["cls_capt"])           # model.py:926: no sims for cls
+    assert [len(r) for r in out["bbox_capts"]] == [3, 3] and [len(r) for r in out["bbox_sims"]] == [3, 3]
+    assert all(len(s) == 2 and s[0] >= s[1] for r in out["bbox_sims"] for s in r)
+    with pytest.raises(ValueError):
+        _model(224, True, max_batch=2)(imgs, return_n_best_sims=2)    # not a calculate_argmax_text model
