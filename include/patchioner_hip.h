@@ -184,6 +184,26 @@ int pio_revert_transformation(pio_handle h, const float* x_dev, int32_t N, float
 int pio_decode_greedy(pio_handle h, const float* prefix_dev, int32_t N, int32_t steps, int32_t* ids_dev,
                       float* logprob_dev, pio_stream stream);
 
+/* ---- ViECap head (P/src/model.py:1394-1398 -> P/src/viecap/entrypoint.py:98-153) -----------------------
+ * Weights arrive through pio_load_weight under the checkpoint's own names: `mapping_network.*` (ClipCap.py:122-153) and
+ * `gpt.transformer.*` (GPT2LMHeadModel; stored like DeCap's `decoder.transformer.*`).  pio_create: dec_layers = 12,
+ * dec_heads = 12, max_steps >= continuous prompt + hard prompt + 63. */
+/* Entity vocabulary embeddings [K, C] (host; retrieval_categories.py:61-95 normalises them per call: done once here). */
+int pio_viecap_set_entities(pio_handle h, const float* host_embeddings, int32_t K, int32_t C);
+/* continuous_prompt_length of the loaded mapping network (rows of prefix_const), 0 without one */
+int pio_viecap_prompt_length(pio_handle h);
+/* VieCap.forward, first half (entrypoint.py:108-110): feats [N, C] L2-normalised IN PLACE, then
+ * MappingNetwork.forward -> out [N, continuous_prompt_length, 768]. */
+int pio_viecap_mapping(pio_handle h, float* feats, int32_t N, float* out, pio_stream stream);
+/* image_text_simiarlity (retrieval_categories.py:61-95) on the already normalised feats: out [N, K] =
+ * softmax(feats . entities^T / temperature). */
+int pio_viecap_entity_logits(pio_handle h, const float* feats, int32_t N, float temperature, float* out, pio_stream stream);
+/* word_embed + torch.cat + greedy_search (entrypoint.py:126-150, search.py:108-191): cont [N, Lc, 768] soft prompt,
+ * tokens [N, Lt] int32 hard-prompt ids already padded to one length (pad_sequence), soft_first as in the config; `steps`
+ * greedy tokens (64 in the reference) with a KV cache, no attention mask, no early stop -> ids [N, steps] int32. */
+int pio_viecap_decode(pio_handle h, const float* cont, const int32_t* tokens, int32_t N, int32_t Lt, int32_t soft_first,
+                      int32_t steps, int32_t* ids, pio_stream stream);
+
 /* -- measurement: live HIP-event timing of the launches a call makes, on the stream they are launched on.
  *    While enabled every bracketed launch records a (start, stop) event pair; pio_profile_read waits for the
  *    recorded events of one class and returns the summed device time, the launch count and the ALGORITHMIC

@@ -416,6 +416,40 @@ class DeCapOracle:
                          self.eps)
         return x @ w["decoder.transformer.wte.weight"].t()
 
+    def gpt2_logits_cached(self, inputs_embeds: torch.Tensor, past=None):
+        """GPT2LMHeadModel(inputs_embeds=..., past_key_values=past, use_cache=True) as the ViECap greedy search calls it
+        (P/src/viecap/search.py:152-164): the new positions attend to the cached keys / values and to themselves causally.
+        -> (logits of the LAST new position [N, V], new past = list of (keys, values) [N, H, S_total, hd] per layer)."""
+        w, E, H = self.w, self.E, self.n_head
+        N, S, _ = inputs_embeds.shape
+        S0 = 0 if past is None else past[0][0].shape[2]
+        x = inputs_embeds + w["decoder.transformer.wpe.weight"][S0:S0 + S].unsqueeze(0)
+        mask = torch.tril(torch.ones(S0 + S, S0 + S, dtype=torch.bool))[S0:]
+        new_past = []
+        for l in range(self.n_layer):
+            p = "decoder.transformer.h.%d." % l
+            y = F.layer_norm(x, (E,), w[p + "ln_1.weight"], w[p + "ln_1.bias"], self.eps)
+            qkv = y @ w[p + "attn.c_attn.weight"] + w[p + "attn.c_attn.bias"]
+            q, k, v = qkv.split(E, dim=2)
+            q = q.view(N, S, H, E // H).transpose(1, 2)
+            k = k.view(N, S, H, E // H).transpose(1, 2)
+            v = v.view(N, S, H, E // H).transpose(1, 2)
+            if past is not None:
+                k = torch.cat((past[l][0], k), dim=2)
+                v = torch.cat((past[l][1], v), dim=2)
+            new_past.append((k, v))
+            att = (q @ k.transpose(-1, -2)) / math.sqrt(E // H)
+            att = att.masked_fill(~mask, torch.finfo(att.dtype).min).softmax(dim=-1)
+            y = (att @ v).transpose(1, 2).reshape(N, S, E)
+            y = y @ w[p + "attn.c_proj.weight"] + w[p + "attn.c_proj.bias"]
+            x = x + y
+            y = F.layer_norm(x, (E,), w[p + "ln_2.weight"], w[p + "ln_2.bias"], self.eps)
+            y = gelu_new(y @ w[p + "mlp.c_fc.weight"] + w[p + "mlp.c_fc.bias"])
+            y = y @ w[p + "mlp.c_proj.weight"] + w[p + "mlp.c_proj.bias"]
+            x = x + y
+        x = F.layer_norm(x[:, -1], (E,), w["decoder.transformer.ln_f.weight"], w["decoder.transformer.ln_f.bias"], self.eps)
+        return x @ w["decoder.transformer.wte.weight"].t(), new_past
+
     def decode_ids(self, clip_features: torch.Tensor, entry_length: int = 30):
         """P/src/decap/decap.py:116-155: 30 full forwards over the growing sequence; returns
         (ids [N,30] int64, per-token log-probs [N,30], top-2 logit margin [N,30])."""
@@ -578,3 +612,132 @@ class PatchionerOracle:
             emb = trace_embeds(patches, traces, self_attn if use_attention_tracing else None)
             outs["trace_capts"] = self.caption_tokens(emb)
         return outs
+
+
+# --------------------------------------------------------------------------------------------
+# f1  ViECap head (P/src/viecap): mapping network, entity retrieval, hard prompt, greedy search
+# --------------------------------------------------------------------------------------------
+
+
+class ViECapOracle:
+    """``VieCap.forward`` (P/src/viecap/entrypoint.py:98-153) for the GPT-2 / greedy-search configuration, with the pieces
+    it calls restated: ``MappingNetwork`` (ClipCap.py:122-153 over :8-120), ``image_text_simiarlity`` / ``top_k_categories``
+    (retrieval_categories.py:61-116), ``compose_discrete_prompts`` (utils.py:55-74), ``greedy_search`` (search.py:108-191,
+    with the KV cache the reference itself uses there).  ``w`` = the
+    checkpoint's state dict (``mapping_network.*``, ``gpt.*``); ``tokenizer`` = any object with ``encode`` / ``decode`` /
+    ``pad_token_id``."""
+
+    def __init__(self, w: Dict[str, torch.Tensor], tokenizer, entities_text: Sequence[str], texts_embeddings: torch.Tensor,
+                 continuous_prompt_length: int = 10, clip_project_length: int = 10, temperature: float = 0.01, top_k: int = 3,
+                 threshold: float = 0.2, using_hard_prompt: bool = False, soft_prompt_first: bool = False,
+                 map_heads: int = 8, gpt_heads: int = 12):
+        self.w = {k: v.detach().float().cpu() for k, v in w.items()}
+        self.tok = tokenizer
+        self.entities_text = list(entities_text)
+        self.texts_embeddings = texts_embeddings.detach().float().cpu().clone()
+        self.Lc, self.Lp = continuous_prompt_length, clip_project_length
+        self.temperature, self.top_k, self.threshold = temperature, top_k, threshold
+        self.using_hard_prompt, self.soft_prompt_first = using_hard_prompt, soft_prompt_first
+        self.map_heads = map_heads
+        self.gpt = DeCapOracle({("decoder." + k[4:]): v for k, v in self.w.items() if k.startswith("gpt.")}, n_head=gpt_heads)
+        self.map_layers = 1 + max(int(k.split(".")[3]) for k in self.w if k.startswith("mapping_network.transformer.layers."))
+        self.last = {}
+
+    # ---- ClipCap.py:122-153
+    def mapping_network(self, x: torch.Tensor) -> torch.Tensor:
+        w = self.w
+        E = w["mapping_network.prefix_const"].shape[1]
+        h = F.linear(x, w["mapping_network.linear.weight"], w["mapping_network.linear.bias"]).view(x.shape[0], self.Lp, -1)
+        prefix = w["mapping_network.prefix_const"].unsqueeze(0).expand(x.shape[0], -1, -1)
+        q = torch.cat((h, prefix), dim=1)
+        H = self.map_heads
+        for l in range(self.map_layers):
+            p = "mapping_network.transformer.layers.%d." % l
+            y = F.layer_norm(q, (E,), w[p + "norm1.weight"], w[p + "norm1.bias"], 1e-5)
+            b, n, _ = y.shape
+            queries = F.linear(y, w[p + "attn.to_queries.weight"]).reshape(b, n, H, E // H)
+            kv = F.linear(y, w[p + "attn.to_keys_values.weight"]).reshape(b, n, 2, H, E // H)
+            keys, values = kv[:, :, 0], kv[:, :, 1]
+            att = torch.einsum("bnhd,bmhd->bnmh", queries, keys) * (E // H) ** -0.5
+            att = att.softmax(dim=2)
+            o = torch.einsum("bnmh,bmhd->bnhd", att, values).reshape(b, n, E)
+            q = q + F.linear(o, w[p + "attn.project.weight"], w[p + "attn.project.bias"])
+            y = F.layer_norm(q, (E,), w[p + "norm2.weight"], w[p + "norm2.bias"], 1e-5)
+            y = F.linear(F.relu(F.linear(y, w[p + "mlp.fc1.weight"], w[p + "mlp.fc1.bias"])), w[p + "mlp.fc2.weight"], w[p + "mlp.fc2.bias"])
+            q = q + y
+        return q[:, self.Lp:, :]
+
+    # ---- retrieval_categories.py:61-116
+    def entity_probs(self, feats: torch.Tensor) -> torch.Tensor:
+        f = feats.float().clone()
+        t = self.texts_embeddings
+        f /= f.norm(dim=-1, keepdim=True)
+        t /= t.norm(dim=-1, keepdim=True)            # in place on the stored embeddings, as the reference does per call
+        return torch.softmax(f @ t.transpose(1, 0) / self.temperature, dim=-1)
+
+    def detect(self, probs_row: torch.Tensor) -> List[str]:
+        vals, idx = torch.topk(probs_row, k=self.top_k, dim=-1)
+        out = []
+        for j in range(self.top_k):
+            if vals[j] < self.threshold:
+                break
+            out.append(self.entities_text[int(idx[j])])
+        return out
+
+    @staticmethod
+    def prompt_text(entities: Sequence[str]) -> str:      # utils.py:55-74
+        if len(entities) == 0:
+            return "There are something in image."
+        s = ""
+        for e in entities:
+            s += " " + e + ","
+        return "There are" + s[:-1] + " in image."
+
+    def forward(self, image_features: torch.Tensor):
+        """-> captions (a str for a single feature, search.py:172-181); ``self.last``: soft prompt, entity probabilities,
+        prompt token ids (padded), generated ids [N, 64], top-2 logit margins per step."""
+        pad_id = self.tok.pad_token_id if self.tok.pad_token_id is not None else 0
+        image_features /= image_features.norm(2, dim=-1, keepdim=True)           # in place (entrypoint.py:108)
+        cont = self.mapping_network(image_features)
+        wte = self.gpt.w["decoder.transformer.wte.weight"]
+        tokens = None
+        if self.using_hard_prompt:
+            probs = self.entity_probs(image_features)
+            rows = [self.tok.encode(self.prompt_text(self.detect(probs[i]))) for i in range(image_features.shape[0])]
+            L = max(len(r) for r in rows)
+            tokens = torch.full((len(rows), L), pad_id, dtype=torch.long)
+            for i, r in enumerate(rows):
+                tokens[i, :len(r)] = torch.tensor(r)
+            disc = wte[tokens]
+            emb = torch.cat((cont, disc), dim=1) if self.soft_prompt_first else torch.cat((disc, cont), dim=1)
+            self.last["entity_probs"] = probs
+        else:
+            emb = cont
+        eos = [self.tok.encode(e)[-1] for e in (".", " .")]
+        ids, margins = [], []
+        b = emb.shape[0]
+        early = None
+        logits, past = self.gpt.gpt2_logits_cached(emb)            # search.py:152-155: the prompt
+        for step in range(64):                                    # search.py:150-181
+            nxt = torch.argmax(logits, dim=-1, keepdim=True)
+            top2 = logits.topk(2, dim=-1).values
+            margins.append((top2[:, 0] - top2[:, 1]).unsqueeze(1))
+            ids.append(nxt)
+            if b == 1 and int(nxt) in eos and early is None:
+                early = step                                      # the reference returns here; decoding on changes nothing it returns
+            if step < 63:
+                logits, past = self.gpt.gpt2_logits_cached(wte[nxt], past)
+        ids, margins = torch.cat(ids, 1), torch.cat(margins, 1)
+        self.last.update(cont=cont, prompt_tokens=tokens, ids=ids, margins=margins)
+        if b == 1:
+            r = ids[0].tolist()
+            return self.tok.decode(r[:early + 1] if early is not None else r)
+        out = []
+        for r in ids.tolist():
+            i = len(r) - 1
+            for j, t in enumerate(r):
+                if t in eos:
+                    i = j
+                    break
+            out.append(self.tok.decode(r[:i + 1]))
+        return out

@@ -61,6 +61,11 @@ SIGNATURES = {
     "pio_gaussian_map": (c_int32, [c_void_p, c_float, c_void_p, c_void_p]),
     "pio_mem_project": (c_int32, [c_void_p, c_void_p, c_int32, c_float, c_int32, c_void_p, c_int32, c_void_p,
                                   c_void_p]),
+    "pio_viecap_prompt_length": (c_int32, [c_void_p]),
+    "pio_viecap_set_entities": (c_int32, [c_void_p, c_void_p, c_int32, c_int32]),
+    "pio_viecap_mapping": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "pio_viecap_entity_logits": (c_int32, [c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p]),
+    "pio_viecap_decode": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "pio_mem_topk": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "pio_revert_transformation": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "pio_decode_greedy": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

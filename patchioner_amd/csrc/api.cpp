@@ -110,6 +110,17 @@ struct pio_context {
   bool use_graph = true;
   // inversion
   float *A_pinv = nullptr, *inv_b = nullptr;
+  // ViECap head (viecap.hip): mapping network weights / workspaces, entity embeddings, prompt buffer
+  bool has_clip_project = false, has_map = false;
+  int map_C = 0, map_Lp = 0, map_Lc = 0, map_hidden = 0, map_layers = 0;
+  float *map_lin_w = nullptr, *map_lin_b = nullptr, *map_prefix = nullptr;
+  std::vector<ViecapMapLayerW> ml;
+  float *map_lin = nullptr, *map_x = nullptr, *map_ln = nullptr, *map_q = nullptr, *map_kv = nullptr, *map_att = nullptr, *map_hid = nullptr;
+  float* ent = nullptr; int ent_K = 0;            // [K][C] L2-normalised entity text embeddings
+  float* prompt_buf = nullptr;                    // [max_prefixes][max_steps][E]
+  int32_t* tok_buf = nullptr;                     // [max_prefixes][max_steps]
+  struct PKey { int N, P, steps; bool operator<(const PKey& o) const { return N != o.N ? N < o.N : (P != o.P ? P < o.P : steps < o.steps); } };
+  std::map<PKey, hipGraphExec_t> pgraphs;
   // memory bank
   float* bank = nullptr; float* bank_inv = nullptr; int64_t bank_rows = 0; int bank_dim = 0;
   float *part_acc = nullptr, *part_ml = nullptr, *sims = nullptr;
@@ -303,10 +314,13 @@ int finalize_decoder(pio_context* c) {
   if (E != 768) return fail(PIO_ERR_SHAPE, "decoder kernels are built for n_embd = 768 (the DeCap GPT-2 config)");
   const HostTensor *t, *tw, *tb, *tl, *tlb;
   int rc;
-  if ((rc = need(c, "clip_project.model.0.weight", {E, PS}, &t))) return rc;
-  if ((rc = upload_f32(c, t->data.data(), (size_t)E * PS, &c->clip_w))) return rc;
-  if ((rc = need(c, "clip_project.model.0.bias", {E}, &t))) return rc;
-  if ((rc = upload_f32(c, t->data.data(), E, &c->clip_b))) return rc;
+  if (find(c, "clip_project.model.0.weight")) {        // DeCap's prefix projection; a ViECap language model has none
+    if ((rc = need(c, "clip_project.model.0.weight", {E, PS}, &t))) return rc;
+    if ((rc = upload_f32(c, t->data.data(), (size_t)E * PS, &c->clip_w))) return rc;
+    if ((rc = need(c, "clip_project.model.0.bias", {E}, &t))) return rc;
+    if ((rc = upload_f32(c, t->data.data(), E, &c->clip_b))) return rc;
+    c->has_clip_project = true;
+  }
   if ((rc = need(c, "decoder.transformer.wte.weight", {V, E}, &tw))) return rc;
   if ((rc = upload_f32(c, tw->data.data(), (size_t)V * E, &c->wte))) return rc;
   if ((rc = need(c, "decoder.transformer.wpe.weight", {P, E}, &t))) return rc;
@@ -408,6 +422,59 @@ int alloc_decoder_workspaces(pio_context* c) {
   return PIO_OK;
 }
 
+// MappingNetwork of the ViECap head (P/src/viecap/ClipCap.py:122-153); 8 heads (ClipCaptionModel's default, :171)
+int finalize_viecap_map(pio_context* c) {
+  const int E = c->cfg.dec_embd;
+  const HostTensor* t;
+  int rc;
+  const HostTensor* lw = find(c, "mapping_network.linear.weight");
+  const HostTensor* pc = find(c, "mapping_network.prefix_const");
+  if (!lw || !pc || lw->shape.size() != 2 || pc->shape.size() != 2 || pc->shape[1] != E || lw->shape[0] % E != 0)
+    return fail(PIO_ERR_SHAPE, "mapping_network.linear.weight [Lp*E, C] / prefix_const [Lc, E] missing or mis-shaped");
+  c->map_C = (int)lw->shape[1]; c->map_Lp = (int)(lw->shape[0] / E); c->map_Lc = (int)pc->shape[0];
+  if (c->map_C % 32 != 0 || c->map_Lp + c->map_Lc > 32) return fail(PIO_ERR_SHAPE, "mapping network: C % 32 != 0 or more than 32 tokens");
+  if ((rc = upload_f32(c, lw->data.data(), lw->data.size(), &c->map_lin_w))) return rc;
+  if ((rc = need(c, "mapping_network.linear.bias", {(int64_t)c->map_Lp * E}, &t))) return rc;
+  if ((rc = upload_f32(c, t->data.data(), t->data.size(), &c->map_lin_b))) return rc;
+  if ((rc = upload_f32(c, pc->data.data(), pc->data.size(), &c->map_prefix))) return rc;
+  int L = 0;
+  while (find(c, "mapping_network.transformer.layers." + std::to_string(L) + ".norm1.weight")) ++L;
+  if (L < 1) return fail(PIO_ERR_SHAPE, "mapping network without transformer layers");
+  const HostTensor* f1 = find(c, "mapping_network.transformer.layers.0.mlp.fc1.weight");
+  if (!f1 || f1->shape.size() != 2) return fail(PIO_ERR_SHAPE, "mapping network: mlp.fc1.weight missing");
+  const int H = (int)f1->shape[0];
+  if (H % 32 != 0) return fail(PIO_ERR_SHAPE, "mapping network: hidden size % 32 != 0");
+  c->map_layers = L; c->map_hidden = H;
+  c->ml.resize(L);
+  for (int l = 0; l < L; ++l) {
+    const std::string pre = "mapping_network.transformer.layers." + std::to_string(l) + ".";
+    ViecapMapLayerW& w = c->ml[l];
+    struct F { const char* key; std::vector<int64_t> shape; const float** dst; };
+    F fs[] = {{"norm1.weight", {E}, &w.n1w}, {"norm1.bias", {E}, &w.n1b}, {"attn.to_queries.weight", {E, E}, &w.q_w},
+              {"attn.to_keys_values.weight", {2 * E, E}, &w.kv_w}, {"attn.project.weight", {E, E}, &w.proj_w},
+              {"attn.project.bias", {E}, &w.proj_b}, {"norm2.weight", {E}, &w.n2w}, {"norm2.bias", {E}, &w.n2b},
+              {"mlp.fc1.weight", {H, E}, &w.fc1_w}, {"mlp.fc1.bias", {H}, &w.fc1_b}, {"mlp.fc2.weight", {E, H}, &w.fc2_w},
+              {"mlp.fc2.bias", {E}, &w.fc2_b}};
+    for (auto& f : fs) {
+      if ((rc = need(c, pre + f.key, f.shape, &t))) return rc;
+      float* d = nullptr;
+      if ((rc = upload_f32(c, t->data.data(), t->data.size(), &d))) return rc;
+      *f.dst = d;
+    }
+    if (find(c, pre + "attn.to_queries.bias")) return fail(PIO_ERR_SHAPE, "mapping network with biased q / kv projections (the reference builds them bias-free)");
+  }
+  const size_t N = c->cfg.max_prefixes, M = N * (c->map_Lp + c->map_Lc);
+  if ((rc = c->dmalloc(&c->map_lin, N * c->map_Lp * E))) return rc;
+  if ((rc = c->dmalloc(&c->map_x, M * E))) return rc;
+  if ((rc = c->dmalloc(&c->map_ln, M * E))) return rc;
+  if ((rc = c->dmalloc(&c->map_q, M * E))) return rc;
+  if ((rc = c->dmalloc(&c->map_kv, M * 2 * E))) return rc;
+  if ((rc = c->dmalloc(&c->map_att, M * E))) return rc;
+  if ((rc = c->dmalloc(&c->map_hid, M * H))) return rc;
+  c->has_map = true;
+  return PIO_OK;
+}
+
 bool is_ignorable_key(const std::string& k) {
   auto ends = [&](const char* s) { size_t n = strlen(s); return k.size() >= n && k.compare(k.size() - n, n, s) == 0; };
   return k == "mask_token" || k == "decoder.lm_head.weight" || ends(".attn.bias") || ends(".attn.masked_bias");
@@ -418,7 +485,8 @@ bool is_known_key(const std::string& k) {
                                 "patch_embed.proj.bias", "norm.weight", "norm.bias", "talk2dino.A_pinv",
                                 "talk2dino.b"};
   for (auto e : exact) if (k == e) return true;
-  return k.rfind("blocks.", 0) == 0 || k.rfind("decoder.transformer.", 0) == 0 || k.rfind("clip_project.model.0.", 0) == 0;
+  return k.rfind("blocks.", 0) == 0 || k.rfind("decoder.transformer.", 0) == 0 || k.rfind("clip_project.model.0.", 0) == 0 ||
+         k.rfind("mapping_network.", 0) == 0;
 }
 
 // ---- Pillow's resampling coefficients (src/libImaging/Resample.c: bicubic_filter, precompute_coeffs,
@@ -514,8 +582,8 @@ int pio_create(const pio_config* cfg, pio_handle* out) {
     return fail(PIO_ERR_INVALID_ARG, "pio_create: backbone head_dim must be 64 (embed_dim = 64 * num_heads)");
   if (cfg->crop_dim % cfg->patch_size != 0)
     return fail(PIO_ERR_INVALID_ARG, "pio_create: crop_dim must be a multiple of patch_size");
-  if (cfg->max_batch < 1 || cfg->max_prefixes < 1 || cfg->max_prefixes > 128 || cfg->max_steps < 1 || cfg->max_steps > 64)
-    return fail(PIO_ERR_INVALID_ARG, "pio_create: capacities out of range (prefixes <= 128, steps <= 64)");
+  if (cfg->max_batch < 1 || cfg->max_prefixes < 1 || cfg->max_prefixes > 128 || cfg->max_steps < 1 || cfg->max_steps > 128)
+    return fail(PIO_ERR_INVALID_ARG, "pio_create: capacities out of range (prefixes <= 128, decoder positions <= 128)");
   if (cfg->readout_heads != 16 && cfg->readout_heads * 64 != cfg->embed_dim)
     return fail(PIO_ERR_INVALID_ARG, "pio_create: readout_heads must be 16, or embed_dim / 64 (ViT-S: 6)");
   int ndev = 0;
@@ -558,6 +626,7 @@ int pio_clone_decoder(pio_handle src, pio_handle* out) {
   c->head_w = src->head_w; c->head_c = src->head_c; c->head_d = src->head_d;
   c->head_w16 = src->head_w16; c->head_w16_unscale = src->head_w16_unscale; c->head_bound_coef = src->head_bound_coef;
   c->dl = src->dl;
+  c->has_clip_project = src->has_clip_project;
   hipError_t e = hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return fail(PIO_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
   const int rc = alloc_decoder_workspaces(c);
@@ -583,6 +652,7 @@ int pio_destroy(pio_handle c) {
   (void)hipSetDevice(c->cfg.device);
   (void)hipDeviceSynchronize();
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
+  for (auto& g : c->pgraphs) (void)hipGraphExecDestroy(g.second);
   for (void* p : c->allocs) (void)hipFree(p);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto& sl : c->prep_slots) {
@@ -600,7 +670,10 @@ int pio_destroy(pio_handle c) {
 int pio_load_weight(pio_handle c, const char* key, const float* host_data, const int64_t* shape, int32_t ndim) {
   if (!c || !key || !host_data || (ndim > 0 && !shape)) return fail(PIO_ERR_INVALID_ARG, "pio_load_weight: null argument");
   if (c->finalized) return fail(PIO_ERR_INVALID_ARG, "pio_load_weight: weights already finalized");
-  const std::string k(key);
+  std::string k(key);
+  // a ViECap checkpoint (ClipCaptionModel.state_dict(), P/src/viecap/ClipCap.py:155-200) names its language model
+  // `gpt.*`: the same GPT2LMHeadModel keys the DeCap checkpoint has under `decoder.*`
+  if (k.rfind("gpt.", 0) == 0) k = "decoder." + k.substr(4);
   if (is_ignorable_key(k)) return PIO_OK;
   if (!is_known_key(k)) return fail(PIO_ERR_UNKNOWN_WEIGHT, "unknown weight key '" + k + "'");
   HostTensor t;
@@ -620,6 +693,9 @@ int pio_finalize_weights(pio_handle c) {
   }
   if (find(c, "decoder.transformer.wte.weight")) {
     if ((rc = finalize_decoder(c))) return rc;
+  }
+  if (find(c, "mapping_network.linear.weight")) {
+    if ((rc = finalize_viecap_map(c))) return rc;
   }
   if (find(c, "talk2dino.A_pinv")) {
     const HostTensor* t;
@@ -893,10 +969,10 @@ int pio_revert_transformation(pio_handle c, const float* x, int32_t N, float* ou
 int pio_decode_greedy(pio_handle c, const float* prefix, int32_t N, int32_t steps, int32_t* ids, float* logprob,
                       pio_stream stream) {
   if (!c || !prefix || !ids) return fail(PIO_ERR_INVALID_ARG, "pio_decode_greedy: null argument");
-  if (!c->has_dec) return fail(PIO_ERR_NOT_READY, "pio_decode_greedy: decoder weights not loaded");
+  if (!c->has_dec || !c->has_clip_project) return fail(PIO_ERR_NOT_READY, "pio_decode_greedy: decoder weights (with clip_project) not loaded");
   if (N < 1 || N > c->cfg.max_prefixes) return fail(PIO_ERR_CAPACITY, "pio_decode_greedy: N above max_prefixes");
   if (logprob && N > 64) return fail(PIO_ERR_CAPACITY, "pio_decode_greedy: log-probabilities are built for <= 64 prefixes per call");
-  if (steps < 1 || steps > c->cfg.max_steps) return fail(PIO_ERR_CAPACITY, "pio_decode_greedy: steps above max_steps");
+  if (steps < 1 || steps > c->cfg.max_steps || steps > 64) return fail(PIO_ERR_CAPACITY, "pio_decode_greedy: steps above max_steps");
   HIP_OK(hipSetDevice(c->cfg.device));
   hipStream_t s = (hipStream_t)stream;
   const int E = c->cfg.dec_embd, PS = c->cfg.prefix_size;
@@ -938,6 +1014,103 @@ int pio_decode_greedy(pio_handle c, const float* prefix, int32_t N, int32_t step
   }
   HIP_OK(hipMemcpyAsync(ids, c->ids_buf, (size_t)N * steps * 4, hipMemcpyDeviceToDevice, s));
   if (logprob) HIP_OK(hipMemcpyAsync(logprob, c->logprob_buf, (size_t)N * steps * 4, hipMemcpyDeviceToDevice, s));
+  return PIO_OK;
+}
+
+int pio_viecap_set_entities(pio_handle c, const float* host_embeddings, int32_t K, int32_t C) {
+  if (!c || !host_embeddings || K < 1) return fail(PIO_ERR_INVALID_ARG, "pio_viecap_set_entities: bad argument");
+  if (!c->has_map || C != c->map_C) return fail(PIO_ERR_SHAPE, "pio_viecap_set_entities: width differs from the mapping network's input");
+  if (c->ent) return fail(PIO_ERR_INVALID_ARG, "entity embeddings already set");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  int rc;
+  if ((rc = upload_f32(c, host_embeddings, (size_t)K * C, &c->ent))) return rc;
+  HIP_OK(launch_l2norm_rows(c->ent, K, C, nullptr));        // texts_embeddings /= norm (retrieval_categories.py:90), once
+  HIP_OK(hipDeviceSynchronize());
+  c->ent_K = K;
+  return PIO_OK;
+}
+
+int pio_viecap_prompt_length(pio_handle c) { return (c && c->has_map) ? c->map_Lc : 0; }
+
+int pio_viecap_mapping(pio_handle c, float* feats, int32_t N, float* out, pio_stream stream) {
+  if (!c || !feats || !out) return fail(PIO_ERR_INVALID_ARG, "pio_viecap_mapping: null argument");
+  if (!c->has_map) return fail(PIO_ERR_NOT_READY, "pio_viecap_mapping: mapping network not loaded");
+  if (N < 1 || N > c->cfg.max_prefixes) return fail(PIO_ERR_CAPACITY, "pio_viecap_mapping: N above max_prefixes");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  HIP_OK(launch_l2norm_rows(feats, N, c->map_C, s));          // image_features /= norm, in place (entrypoint.py:108)
+  ViecapMapArgs a;
+  a.N = N; a.C = c->map_C; a.E = c->cfg.dec_embd; a.Lp = c->map_Lp; a.Lc = c->map_Lc; a.heads = 8; a.layers = c->map_layers;
+  a.hidden = c->map_hidden; a.eps = 1e-5f; a.feats = feats; a.lin_w = c->map_lin_w; a.lin_b = c->map_lin_b; a.prefix_const = c->map_prefix;
+  a.layer = c->ml.data(); a.lin = c->map_lin; a.x = c->map_x; a.ln = c->map_ln; a.q = c->map_q; a.kv = c->map_kv; a.att = c->map_att;
+  a.hid = c->map_hid; a.out = out;
+  HIP_OK(launch_viecap_mapping(a, s));
+  return PIO_OK;
+}
+
+int pio_viecap_entity_logits(pio_handle c, const float* feats, int32_t N, float temperature, float* out, pio_stream stream) {
+  if (!c || !feats || !out) return fail(PIO_ERR_INVALID_ARG, "pio_viecap_entity_logits: null argument");
+  if (!c->ent) return fail(PIO_ERR_NOT_READY, "pio_viecap_entity_logits: entity embeddings not set");
+  if (N < 1 || !(temperature > 0.f)) return fail(PIO_ERR_INVALID_ARG, "pio_viecap_entity_logits: bad argument");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  // softmax(f t^T / T) over the vocabulary (retrieval_categories.py:92-93); f is the already normalised feature
+  HIP_OK(launch_sgemm_tn(feats, c->map_C, c->ent, c->map_C, nullptr, 1.0f / temperature, out, c->ent_K, N, c->ent_K, c->map_C, 0, 0, s));
+  HIP_OK(launch_softmax_rows(out, out, N, c->ent_K, s));
+  return PIO_OK;
+}
+
+int pio_viecap_decode(pio_handle c, const float* cont, const int32_t* tokens, int32_t N, int32_t Lt, int32_t soft_first,
+                      int32_t steps, int32_t* ids, pio_stream stream) {
+  if (!c || !cont || !ids || (Lt > 0 && !tokens)) return fail(PIO_ERR_INVALID_ARG, "pio_viecap_decode: null argument");
+  if (!c->has_dec || !c->has_map) return fail(PIO_ERR_NOT_READY, "pio_viecap_decode: language model / mapping network not loaded");
+  if (N < 1 || N > c->cfg.max_prefixes) return fail(PIO_ERR_CAPACITY, "pio_viecap_decode: N above max_prefixes");
+  const int P = c->map_Lc + Lt;
+  if (Lt < 0 || steps < 1 || steps > 64 || P + steps - 1 > c->cfg.max_steps)
+    return fail(PIO_ERR_CAPACITY, "pio_viecap_decode: prompt + generated positions above max_steps");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  const int E = c->cfg.dec_embd;
+  int rc;
+  if (!c->prompt_buf) {
+    if ((rc = c->dmalloc(&c->prompt_buf, (size_t)c->cfg.max_prefixes * c->cfg.max_steps * E))) return rc;
+    if ((rc = c->dmalloc(&c->tok_buf, (size_t)c->cfg.max_prefixes * c->cfg.max_steps))) return rc;
+  }
+  if (Lt > 0) HIP_OK(hipMemcpyAsync(c->tok_buf, tokens, (size_t)N * Lt * 4, hipMemcpyDeviceToDevice, s));
+  HIP_OK(launch_build_prompt(cont, c->tok_buf, c->wte, N, c->map_Lc, Lt, E, c->cfg.dec_vocab, soft_first, c->prompt_buf, s));
+  DecoderArgs a;
+  a.N = N; a.steps = steps; a.E = E; a.heads = c->cfg.dec_heads; a.layers = c->cfg.dec_layers; a.vocab = c->cfg.dec_vocab;
+  a.prefix_size = c->cfg.prefix_size; a.eps = c->cfg.dec_ln_eps; a.prefix = nullptr; a.clip_w = nullptr; a.clip_b = nullptr;
+  a.wte = c->wte; a.wpe = c->wpe; a.head_w = c->head_w; a.head_c = c->head_c; a.head_d = c->head_d; a.layer = c->dl.data();
+  a.x = c->dx; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.splitk_ws = c->splitk_ws; a.splitk_cnt = c->splitk_cnt;
+  a.kcache = c->kcache; a.vcache = c->vcache; a.max_steps = c->cfg.max_steps; a.logits = c->logits; a.ids = c->ids_buf; a.logprob = nullptr;
+  a.head_w16 = c->head_w16; a.head_w16_unscale = c->head_w16_unscale; a.head_bound_coef = c->head_bound_coef;
+  a.xh = c->dec_xh; a.lm_stats = c->lm_stats; a.lm_gmax = c->lm_gmax; a.pos_base = P - 1;
+  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, 64 * sizeof(unsigned), s));
+  if (c->use_graph) {
+    const pio_context::PKey key{N, P, steps};
+    auto it = c->pgraphs.find(key);
+    if (it == c->pgraphs.end()) {
+      hipGraph_t graph = nullptr;
+      HIP_OK(hipStreamBeginCapture(c->capture_stream, hipStreamCaptureModeThreadLocal));
+      hipError_t le = launch_decode_prompted(a, c->prompt_buf, P, c->capture_stream);
+      hipError_t ce = hipStreamEndCapture(c->capture_stream, &graph);
+      if (le != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return fail(PIO_ERR_HIP, std::string("prompted decode capture: ") + hipGetErrorString(le));
+      }
+      HIP_OK(ce);
+      hipGraphExec_t exec = nullptr;
+      hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      HIP_OK(ie);
+      it = c->pgraphs.emplace(key, exec).first;
+    }
+    HIP_OK(hipGraphLaunch(it->second, s));
+  } else {
+    HIP_OK(launch_decode_prompted(a, c->prompt_buf, P, s));
+  }
+  HIP_OK(hipMemcpyAsync(ids, c->ids_buf, (size_t)N * steps * 4, hipMemcpyDeviceToDevice, s));
   return PIO_OK;
 }
 

@@ -324,14 +324,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? PIO_DEC_GEMM_WAVES : 1) void k
 }
 
 // Causal attention for the new position `pos` of prefix n, head h: appends k,v to the cache and attends
-// over positions 0..pos (pos < 64).  One workgroup per (n, head).
+// over positions 0..pos (pos < 128: 30 for DeCap, prompt + 64 for the ViECap head).  One workgroup per (n, head).
 //   scores : thread (j = tid>>3, seg = tid&7) takes hd/8 channels of key j -> all key loads of a 32-key
 //            pass are in flight at once; 3 shuffles finish the dot product.
 //   output : thread (c4 = tid % (hd/4), jg = tid / (hd/4)) accumulates 4 channels over keys j = jg (mod NJ);
 //            the NJ partial sums meet in LDS.
 __global__ __launch_bounds__(256) void k_dec_attention(const float* __restrict__ qkv, float* kcache, float* vcache,
                                                        int E, int heads, int pos, int max_steps, float* att) {
-  __shared__ float s_sc[64];
+  __shared__ float s_sc[128];
   __shared__ __attribute__((aligned(16))) float s_o[5][256];
   const int n = blockIdx.x / heads, h = blockIdx.x - n * heads;
   const int tid = threadIdx.x;
@@ -377,12 +377,15 @@ __global__ __launch_bounds__(256) void k_dec_attention(const float* __restrict__
     vc[(size_t)pos * E + tid] = vn[tid];
   }
   __syncthreads();
-  if (tid < 64) {                                   // soft-max over the <= 64 scores once, by one wave (pos < 64)
+  if (tid < 64) {                                   // soft-max over the <= 128 scores once, by one wave (two per lane)
     const float sc = tid <= pos ? s_sc[tid] : -INFINITY;
-    const float mx = wave_max(sc);
+    const float sc2 = tid + 64 <= pos ? s_sc[tid + 64] : -INFINITY;
+    const float mx = wave_max(fmaxf(sc, sc2));
     const float e = tid <= pos ? expf(sc - mx) : 0.f;
-    const float inv = 1.0f / wave_sum(e);
+    const float e2 = tid + 64 <= pos ? expf(sc2 - mx) : 0.f;    // pos < 64: 0, and e + 0 is e (the DeCap sums do not change)
+    const float inv = 1.0f / wave_sum(e + e2);
     s_sc[tid] = e * inv;
+    s_sc[tid + 64] = e2 * inv;
   }
   __syncthreads();
   if (jg < NJ) {
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(256) void k_dec_attention(const float* __restrict__
 __global__ __launch_bounds__(256) void k_dec_select(const float* __restrict__ part, int nblk, int N, int E, int step,
                                                     int steps, const float* __restrict__ wte,
                                                     const float* __restrict__ wpe, int32_t* ids, float* logprob,
-                                                    float* x) {
+                                                    float* x, int pos_base) {
   __shared__ float s_v[4];
   __shared__ int s_i[4];
   __shared__ float s_s[4];
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(256) void k_dec_select(const float* __restrict__ pa
 #pragma unroll
   for (int w = 1; w < 4; ++w)
     if (arg_better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
-  for (int d = tid; d < E; d += 256) x[(size_t)n * E + d] = wte[(size_t)bi * E + d] + wpe[(size_t)(step + 1) * E + d];
+  for (int d = tid; d < E; d += 256) x[(size_t)n * E + d] = wte[(size_t)bi * E + d] + wpe[(size_t)(pos_base + step + 1) * E + d];
   if (tid == 0) ids[(size_t)n * steps + step] = bi;
   if (logprob == nullptr) return;                   // block-uniform: the log-probability pass is only run on request
   {
@@ -1240,7 +1243,7 @@ __global__ __launch_bounds__(256) void k_dec_select_filter(const float* __restri
                                                            const float* __restrict__ xrow, const float* __restrict__ W /*[V][E] LN-folded*/,
                                                            const float* __restrict__ dvec, const float* __restrict__ cvec, int E, int step,
                                                            int steps, const float* __restrict__ wte, const float* __restrict__ wpe,
-                                                           int32_t* ids, float* x) {
+                                                           int32_t* ids, float* x, int pos_base) {
   constexpr int CAND = 512;
   __shared__ float s_v[4];
   __shared__ int s_i[4];
@@ -1312,7 +1315,7 @@ __global__ __launch_bounds__(256) void k_dec_select_filter(const float* __restri
       if (arg_better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
     best_i = bi < V ? bi : 0;
   }
-  for (int d = tid; d < E; d += 256) x[(size_t)n * E + d] = wte[(size_t)best_i * E + d] + wpe[(size_t)(step + 1) * E + d];
+  for (int d = tid; d < E; d += 256) x[(size_t)n * E + d] = wte[(size_t)best_i * E + d] + wpe[(size_t)(pos_base + step + 1) * E + d];
   if (tid == 0) ids[(size_t)n * steps + step] = best_i;
 }
 
@@ -1354,7 +1357,7 @@ static hipError_t launch_lmhead_filtered(const DecoderArgs& a, int step, hipStre
   const int NG = ceil_div(a.vocab, 16), NGp = round_up(NG, 64);
   if (NG > 4096) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_dec_select_filter, dim3(a.N), dim3(256), 0, s, a.logits, a.lm_gmax, a.vocab, Vp, NG, NGp, a.lm_stats, a.x,
-                     a.head_w, a.head_d, a.head_c, a.E, step, a.steps, a.wte, a.wpe, a.ids, a.x);
+                     a.head_w, a.head_d, a.head_c, a.E, step, a.steps, a.wte, a.wpe, a.ids, a.x, a.pos_base);
   return hipGetLastError();
 }
 
@@ -1374,36 +1377,73 @@ hipError_t launch_lmhead(const float* W, const float* X, int N, int V, int E, co
   return dec_gemm<DE_ARGMAX, 1>(W, X, N, V, E, dvec, part, nullptr, cvec, eps, nullptr, nullptr, s);
 }
 
+// One new position `pos` of every prefix through the transformer layers (x in place; keys / values appended at `pos`).
+static hipError_t dec_layers_step(const DecoderArgs& a, int pos, hipStream_t s) {
+  const int N = a.N, E = a.E;
+  for (int l = 0; l < a.layers; ++l) {
+    const DecLayerW& w = a.layer[l];
+    float* kc = a.kcache + (size_t)l * N * a.max_steps * E;
+    float* vc = a.vcache + (size_t)l * N * a.max_steps * E;
+    PIO_TRY((dec_gemm<DE_STORE, 1>(w.attn_w, a.x, N, 3 * E, E, w.attn_d, a.qkv, nullptr, w.attn_c, a.eps, nullptr, nullptr, s)));
+    hipLaunchKernelGGL(k_dec_attention, dim3(N * a.heads), dim3(256), 0, s, a.qkv, kc, vc, E, a.heads, pos, a.max_steps, a.att);
+    PIO_TRY((dec_gemm<DE_RESID, 0>(w.proj_w, a.att, N, E, E, w.proj_b, a.x, nullptr, nullptr, 0.f, nullptr, nullptr, s)));
+    PIO_TRY((dec_gemm<DE_GELU, 1>(w.fc_w, a.x, N, 4 * E, E, w.fc_d, a.hid, nullptr, w.fc_c, a.eps, nullptr, nullptr, s)));
+    PIO_TRY((dec_gemm<DE_RESID, 0>(w.fc2_w, a.hid, N, E, 4 * E, w.fc2_b, a.x, nullptr, nullptr, 0.f, a.splitk_ws, a.splitk_cnt, s)));
+  }
+  return hipSuccess;
+}
+
+// LM head on x -> ids[.][step] (+ log-prob) and the next position's input x = wte[id] + wpe[pos_base + step + 1]
+static hipError_t dec_head_step(const DecoderArgs& a, int step, bool filtered, hipStream_t s) {
+  if (filtered) return launch_lmhead_filtered(a, step, s);
+  int nblk = 0;
+  PIO_TRY(launch_lmhead(a.head_w, a.x, a.N, a.vocab, a.E, a.head_d, a.head_c, a.eps, a.logits, &nblk, s));
+  hipLaunchKernelGGL(k_dec_select, dim3(a.N), dim3(256), 0, s, a.logits, nblk, a.N, a.E, step, a.steps, a.wte, a.wpe, a.ids,
+                     a.logprob, a.x, a.pos_base);
+  return hipGetLastError();
+}
+
+static bool dec_args_ok(const DecoderArgs& a, bool filtered, int positions) {
+  return positions <= a.max_steps && positions <= 128 && a.steps <= 64 && a.E == 768 && (a.E / a.heads) % 32 == 0 &&
+         (a.E / a.heads) <= 256 && a.N <= (filtered ? 128 : 64) && ceil_div(a.vocab, 16) <= 4096;
+}
+
 hipError_t launch_decode_greedy(const DecoderArgs& a, hipStream_t s) {
   const int N = a.N, E = a.E;
   const bool filtered = PIO_LMHEAD_FILTER && a.logprob == nullptr && a.head_w16 != nullptr;
   // 65..128 prefixes only through the filtered (ids-only) head; the exact head is built for <= 64
-  if (a.steps > a.max_steps || a.steps > 64 || E != 768 || (E / a.heads) % 32 != 0 || (E / a.heads) > 256 ||
-      N > (filtered ? 128 : 64))
-    return hipErrorInvalidValue;
-  if (ceil_div(a.vocab, 16) > 4096) return hipErrorInvalidValue;
+  if (!dec_args_ok(a, filtered, a.steps) || a.pos_base != 0) return hipErrorInvalidValue;
   // step 0 input: clip_project(prefix) + wpe[0]   (decap.py:124; GPT-2 adds wpe to inputs_embeds)
   PIO_TRY((dec_gemm<DE_EMBED, 0>(a.clip_w, a.prefix, N, E, a.prefix_size, a.clip_b, a.x, a.wpe, nullptr, 0.f, nullptr, nullptr, s)));
   for (int step = 0; step < a.steps; ++step) {
-    for (int l = 0; l < a.layers; ++l) {
-      const DecLayerW& w = a.layer[l];
-      float* kc = a.kcache + (size_t)l * N * a.max_steps * E;
-      float* vc = a.vcache + (size_t)l * N * a.max_steps * E;
-      PIO_TRY((dec_gemm<DE_STORE, 1>(w.attn_w, a.x, N, 3 * E, E, w.attn_d, a.qkv, nullptr, w.attn_c, a.eps, nullptr, nullptr, s)));
-      hipLaunchKernelGGL(k_dec_attention, dim3(N * a.heads), dim3(256), 0, s, a.qkv, kc, vc, E, a.heads, step,
-                         a.max_steps, a.att);
-      PIO_TRY((dec_gemm<DE_RESID, 0>(w.proj_w, a.att, N, E, E, w.proj_b, a.x, nullptr, nullptr, 0.f, nullptr, nullptr, s)));
-      PIO_TRY((dec_gemm<DE_GELU, 1>(w.fc_w, a.x, N, 4 * E, E, w.fc_d, a.hid, nullptr, w.fc_c, a.eps, nullptr, nullptr, s)));
-      PIO_TRY((dec_gemm<DE_RESID, 0>(w.fc2_w, a.hid, N, E, 4 * E, w.fc2_b, a.x, nullptr, nullptr, 0.f, a.splitk_ws, a.splitk_cnt, s)));
-    }
-    if (filtered) {
-      PIO_TRY(launch_lmhead_filtered(a, step, s));
-      continue;
-    }
-    int nblk = 0;
-    PIO_TRY(launch_lmhead(a.head_w, a.x, N, a.vocab, E, a.head_d, a.head_c, a.eps, a.logits, &nblk, s));
-    hipLaunchKernelGGL(k_dec_select, dim3(N), dim3(256), 0, s, a.logits, nblk, N, E, step, a.steps, a.wte, a.wpe,
-                       a.ids, a.logprob, a.x);
+    PIO_TRY(dec_layers_step(a, step, s));
+    PIO_TRY(dec_head_step(a, step, filtered, s));
+  }
+  return hipGetLastError();
+}
+
+// x[n][:] = prompt[n][pos][:] + wpe[pos][:]
+__global__ __launch_bounds__(256) void k_dec_prompt_x(const float* __restrict__ prompt, const float* __restrict__ wpe, int P, int pos, int E,
+                                                      float* x) {
+  const int n = blockIdx.x;
+  for (int d = threadIdx.x; d < E; d += 256) x[(size_t)n * E + d] = prompt[((size_t)n * P + pos) * E + d] + wpe[(size_t)pos * E + d];
+}
+
+// greedy_search of the ViECap head (P/src/viecap/search.py:108-191) with a KV cache: the prompt embeddings [N][P][E]
+// (soft + hard prompt, padded rows included: the reference uses no attention mask) occupy positions 0..P-1; the token
+// chosen from the logits of position P-1+k is ids[.][k] and becomes position P+k.  The reference's 64 iterations run
+// the prompt forward plus 64 single-token forwards and never use the logits of the last one: P + steps - 1 positions here.
+// a.pos_base must be P - 1.
+hipError_t launch_decode_prompted(const DecoderArgs& a, const float* prompt, int P, hipStream_t s) {
+  const bool filtered = PIO_LMHEAD_FILTER && a.logprob == nullptr && a.head_w16 != nullptr;
+  if (P < 1 || a.steps < 1 || a.pos_base != P - 1 || !dec_args_ok(a, filtered, P + a.steps - 1)) return hipErrorInvalidValue;
+  for (int pos = 0; pos < P; ++pos) {
+    hipLaunchKernelGGL(k_dec_prompt_x, dim3(a.N), dim3(256), 0, s, prompt, a.wpe, P, pos, a.E, a.x);
+    PIO_TRY(dec_layers_step(a, pos, s));
+  }
+  for (int step = 0; step < a.steps; ++step) {
+    PIO_TRY(dec_head_step(a, step, filtered, s));            // -> ids[.][step], x = wte[id] + wpe[P + step]
+    if (step + 1 < a.steps) PIO_TRY(dec_layers_step(a, P + step, s));
   }
   return hipGetLastError();
 }

@@ -145,8 +145,34 @@ struct DecoderArgs {
   float* lm_gmax = nullptr;             // [N][round_up(ceil(V/16), 64)] maxima of the approximate logits per 16 columns
   int32_t* ids;      // [N][steps]
   float* logprob;    // [N][steps] or null
+  int pos_base = 0;  // position of the input that produces ids[.][0] (0: the DeCap prefix; P - 1 after a P-position prompt)
 };
 hipError_t launch_decode_greedy(const DecoderArgs& a, hipStream_t s);
+// ViECap greedy search: prompt [N][P][E] at positions 0..P-1, then a.steps greedy tokens (a.pos_base = P - 1)
+hipError_t launch_decode_prompted(const DecoderArgs& a, const float* prompt, int P, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// ViECap head (viecap.hip): mapping network, entity logits, prompt assembly -- all fp32
+// ---------------------------------------------------------------------------------------------
+struct ViecapMapLayerW {
+  const float *n1w, *n1b, *q_w /*[E][E]*/, *kv_w /*[2E][E]*/, *proj_w, *proj_b, *n2w, *n2b, *fc1_w /*[H][E]*/, *fc1_b, *fc2_w /*[E][H]*/, *fc2_b;
+};
+struct ViecapMapArgs {
+  int N, C, E, Lp, Lc, heads, layers, hidden;
+  float eps;
+  const float* feats;        // [N][C], already L2-normalised
+  const float *lin_w /*[Lp*E][C]*/, *lin_b, *prefix_const /*[Lc][E]*/;
+  const ViecapMapLayerW* layer;
+  float *lin, *x, *ln, *q, *kv, *att, *hid;   // workspaces: [N][Lp*E], [M][E] x 4, [M][2E], [M][H] with M = N (Lp + Lc)
+  float* out;                // [N][Lc][E]
+};
+hipError_t launch_viecap_mapping(const ViecapMapArgs& a, hipStream_t s);
+// C = alpha * A W^T (+ bias) (ReLU) (+= C): exact fp32, any M, N; K % 32 == 0
+hipError_t launch_sgemm_tn(const float* A, int lda, const float* W, int ldw, const float* bias, float alpha, float* C, int ldc,
+                           int M, int N, int K, int relu, int resid, hipStream_t s);
+hipError_t launch_build_prompt(const float* cont, const int32_t* tokens, const float* wte, int N, int Lc, int Lt, int E, int V,
+                               int soft_first, float* prompt, hipStream_t s);
+hipError_t launch_l2norm_rows(float* x, int N, int D, hipStream_t s);
 // ---- preprocess.hip: image_transforms on the device (P/src/model.py:347-357; Pillow's 8-bit two-pass resampler) ----
 struct PrepImage {
   int64_t src;                              // byte offset of the image's first pixel in `pixels` (RGB, HWC, row-major)

@@ -427,6 +427,11 @@ hipError_t launch_mem_topk(const float* bank, const float* inv_norm, int64_t M, 
   return hipGetLastError();
 }
 
+hipError_t launch_l2norm_rows(float* x, int N, int D, hipStream_t s) {
+  hipLaunchKernelGGL(k_l2norm_rows, dim3(N), dim3(256), 0, s, x, D);
+  return hipGetLastError();
+}
+
 hipError_t launch_row_inv_norm(const float* bank, int64_t M, int D, float* inv_norm, hipStream_t s) {
   hipLaunchKernelGGL(k_row_inv_norm, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, bank, M, D, inv_norm);
   return hipGetLastError();

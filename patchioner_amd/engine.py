@@ -333,6 +333,41 @@ class Engine:
         check(self.lib.pio_revert_transformation(self.h, ptr(x), x.shape[0], ptr(out), _stream()))
         return out
 
+    # ------------------------------------------------------------------ f1 ViECap head
+    def viecap_set_entities(self, emb: torch.Tensor) -> None:
+        t = emb.detach().to(dtype=torch.float32, device="cpu").contiguous()
+        check(self.lib.pio_viecap_set_entities(self.h, ptr(t), t.shape[0], t.shape[1]))
+        self.viecap_entities = int(t.shape[0])
+
+    def viecap_mapping(self, feats: torch.Tensor) -> torch.Tensor:
+        """feats [N, C] CUDA fp32 contiguous, L2-normalised IN PLACE -> soft prompt [N, Lc, E]."""
+        assert feats.is_cuda and feats.dtype == torch.float32 and feats.is_contiguous()
+        N = feats.shape[0]
+        Lc = self.lib.pio_viecap_prompt_length(self.h)
+        out = torch.empty(N, Lc, self.cfg.dec_embd, device=self.device, dtype=torch.float32)
+        for s in range(0, N, self.max_prefixes):
+            e = min(N, s + self.max_prefixes)
+            check(self.lib.pio_viecap_mapping(self.h, ptr(feats[s:e]), e - s, ptr(out[s:e]), _stream()))
+        return out
+
+    def viecap_entity_logits(self, feats: torch.Tensor, temperature: float) -> torch.Tensor:
+        N = feats.shape[0]
+        out = torch.empty(N, self.viecap_entities, device=self.device, dtype=torch.float32)
+        check(self.lib.pio_viecap_entity_logits(self.h, ptr(feats), N, float(temperature), ptr(out), _stream()))
+        return out
+
+    def viecap_decode(self, cont: torch.Tensor, tokens: Optional[torch.Tensor], soft_first: bool = True, steps: int = 64) -> torch.Tensor:
+        """cont [N, Lc, E] device, tokens [N, Lt] int32 (host or device) or None -> greedy ids [N, steps] int32."""
+        N = cont.shape[0]
+        tok = self._dev(tokens, torch.int32) if tokens is not None else None
+        Lt = int(tok.shape[1]) if tok is not None else 0
+        ids = torch.empty(N, steps, device=self.device, dtype=torch.int32)
+        for s in range(0, N, self.max_prefixes):
+            e = min(N, s + self.max_prefixes)
+            check(self.lib.pio_viecap_decode(self.h, ptr(cont[s:e].contiguous()), ptr(tok[s:e].contiguous()) if tok is not None else None,
+                                             e - s, Lt, 1 if soft_first else 0, int(steps), ptr(ids[s:e]), _stream()))
+        return ids
+
     # ------------------------------------------------------------------ a11/a12 decoder
     def decode_greedy(self, prefix: torch.Tensor, steps: int = 30, want_logprob: bool = False):
         prefix = self._dev(prefix)

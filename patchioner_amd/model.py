@@ -32,7 +32,7 @@ from .engine import Engine
 from .preprocess import make_transforms
 from .tokenizer import ClipDetokenizer
 
-_OUT_OF_SCOPE = ("proxyclip_clipmodel", "viecap_config", "regionclip_config", "invite_config", "denseclip_config",
+_OUT_OF_SCOPE = ("proxyclip_clipmodel", "regionclip_config", "invite_config", "denseclip_config",
                  "alphaclip_config", "clipcap_config")
 
 
@@ -87,7 +87,7 @@ class Patchioner(nn.Module):
                  dino_weights=None, memory_bank=None, synthetic_seed=None, max_batch=16, max_prefixes=64,
                  vit_dtype="fp16", memory_bank_texts=None, **kwargs):
         super().__init__(**kwargs)
-        given = dict(proxyclip_clipmodel=proxyclip_clipmodel, viecap_config=viecap_config,
+        given = dict(proxyclip_clipmodel=proxyclip_clipmodel,
                      regionclip_config=regionclip_config, invite_config=invite_config,
                      denseclip_config=denseclip_config, alphaclip_config=alphaclip_config,
                      clipcap_config=clipcap_config)
@@ -98,7 +98,9 @@ class Patchioner(nn.Module):
             raise NotImplementedError("use_open_clip / online_texts need the CLIP text tower: outside the hot-path scope")
         if dino_model is None or 'dinov2' not in dino_model or 'dinotxt' in dino_model:
             raise ValueError("Unsupported backbone %r: this build implements the DINOv2 ViT-S/B/L-14 family" % (dino_model,))
-        if decoder_weights is None and synthetic_seed is None and not calculate_argmax_text:
+        if viecap_config is not None and viecap_config.get('meacap', False):
+            raise NotImplementedError("MeaCap head (retrieved-caption scene graphs, flan-T5): outside the hot-path scope")
+        if decoder_weights is None and synthetic_seed is None and not calculate_argmax_text and viecap_config is None:
             raise ValueError("decap_weights is required (or synthetic_seed for seeded synthetic weights)")
         self.decoding_method = None
         self.viecap = None
@@ -155,8 +157,16 @@ class Patchioner(nn.Module):
             vit_sd[bk] = torch.cat([bs[x] for x in attention_type], dim=0)
 
         dec_sd = _load_state_dict(decoder_weights)
-        if dec_sd is None and synthetic_seed is not None:
+        if dec_sd is None and synthetic_seed is not None and viecap_config is None:
             dec_sd = W.synth_decap(synthetic_seed + 2, prefix_size)
+        viecap_sd = None
+        if viecap_config is not None:
+            # P/src/model.py:107-113: the ViECap head replaces the DeCap decode (caption_tokens, :1394-1398).  The engine
+            # holds ONE language model: GPT-2-base (12 layers, 12 heads) from the ViECap checkpoint; the DeCap weights the
+            # reference also loads are never used on this path and are not loaded here.
+            from .viecap import load_viecap_weights
+            viecap_sd = load_viecap_weights(viecap_config)
+            dec_sd = None
 
         self.embed_inversion = talk2dino_weights is not None
         inv_sd = {}
@@ -169,17 +179,28 @@ class Patchioner(nn.Module):
             inv_sd["talk2dino.A_pinv"] = (Vh.T @ torch.diag(S_pinv) @ U.T).contiguous()
             inv_sd["talk2dino.b"] = t2d["linear_layer.bias"].float()
 
+        dec_kw = {}
+        if viecap_sd is not None:
+            n_layer = 1 + max(int(k.split(".")[3]) for k in viecap_sd if k.startswith("gpt.transformer.h."))
+            dec_kw = dict(dec_layers=n_layer, dec_heads=12, max_steps=128,
+                          dec_vocab=int(viecap_sd["gpt.transformer.wte.weight"].shape[0]),
+                          dec_positions=int(viecap_sd["gpt.transformer.wpe.weight"].shape[0]))
         self.engine = Engine(embed_dim=self.embed_dim, depth=depth, num_heads=heads,
                              num_registers=self.num_global_tokens - 1, crop_dim=crop_dim, patch_size=patch_size,
                              pretrain_grid=int(math.isqrt(vit_sd["pos_embed"].shape[1] - 1)), prefix_size=prefix_size,
                              max_batch=max_batch, max_prefixes=max_prefixes, vit_dtype=vit_dtype,
-                             device_index=self._device.index, readout_heads=self.num_attn_heads, readout_scale=self.scale)
+                             device_index=self._device.index, readout_heads=self.num_attn_heads, readout_scale=self.scale, **dec_kw)
         self.engine.load_state_dict(vit_sd)
         if dec_sd is not None:                         # calculate_argmax_text without decoder weights: no decoder (model.py:165)
             self.engine.load_state_dict(dec_sd)        # strict=False like the reference (decap.py:214)
+        if viecap_sd is not None:
+            self.engine.load_state_dict({k: v for k, v in viecap_sd.items() if k.startswith(("mapping_network.", "gpt."))})
         if inv_sd:
             self.engine.load_state_dict(inv_sd)
         self.engine.finalize()
+        if viecap_config is not None:
+            from .viecap import VieCapHead
+            self.viecap = VieCapHead(viecap_config, self.engine, clip_model_name)
 
         if support_memory_size > 0:
             if memory_bank is not None:
@@ -541,6 +562,10 @@ class Patchioner(nn.Module):
     def caption_tokens(self, dino_tokens, project=True, return_n_best_sims=None, compute_scores: bool = False):
         """P/src/model.py:1392-1423."""
         eng = self.engine
+        if self.viecap is not None:
+            if return_n_best_sims:
+                raise Exception("return_n_best_sims is not supported with viecap")
+            return self.viecap.forward(dino_tokens, compute_scores=compute_scores)
         if self.im_proj is None:
             project = False
         x = dino_tokens

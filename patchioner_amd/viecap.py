@@ -1,0 +1,250 @@
+"""ViECap head of the reference (``VieCap``, P/src/viecap/entrypoint.py:16-153), host side.
+
+``Patchioner.caption_tokens`` hands the region features to ``self.viecap.forward`` (P/src/model.py:1394-1398).  Everything
+numerical is a C-ABI call (mapping network, entity logits, prompt assembly, KV-cached greedy search: viecap.hip /
+decoder.hip); what stays on the host is what is host work in the reference too: top-k / threshold over the 80-odd entity
+probabilities, composing the hard-prompt STRING, tokenising it, cutting the generated ids at the first full stop and
+detokenising.
+
+There is no network on the target, so nothing is fetched from the HuggingFace hub: the GPT-2 tokenizer comes from local
+``vocab.json`` / ``merges.txt`` (``viecap.tokenizer_path``) or an object with ``encode`` / ``decode`` / ``pad_token_id``
+(``viecap.tokenizer``); the checkpoint (``mapping_network.*`` + ``gpt.*``) from ``viecap.weight_path`` or a state dict
+(``viecap.weights``); the entity vocabulary from the reference's own files under ``files_path`` or
+``viecap.entities_text`` / ``viecap.texts_embeddings``.
+"""
+from __future__ import annotations
+
+import json
+import os
+import pickle
+from argparse import Namespace
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+
+# ------------------------------------------------------------------------------------------------ GPT-2 byte-level BPE
+def _bytes_to_unicode() -> Dict[int, str]:
+    """The printable stand-ins GPT-2's byte-level BPE uses for the 256 byte values (public algorithm)."""
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAD)) + list(range(0xAE, 0x100))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    return dict(zip(bs, (chr(c) for c in cs)))
+
+
+class ByteLevelBPE:
+    """GPT-2's tokenizer (``AutoTokenizer.from_pretrained('gpt2')`` in the reference, entrypoint.py:40) over a local
+    vocabulary: ``vocab`` token string -> id, ``merges`` ranked pairs.  ``encode`` / ``decode`` as the reference uses them
+    (utils.py:72, search.py:141,176-190); ``pad_token_id`` is None for GPT-2, so the reference pads with id 0."""
+
+    PATTERN = r"""'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"""
+
+    def __init__(self, vocab: Dict[str, int], merges: Sequence[Sequence[str]]):
+        import regex
+        self.encoder = dict(vocab)
+        self.decoder = {i: t for t, i in self.encoder.items()}
+        self.ranks = {tuple(m): r for r, m in enumerate(merges)}
+        self.b2u = _bytes_to_unicode()
+        self.u2b = {u: b for b, u in self.b2u.items()}
+        self.pat = regex.compile(self.PATTERN)
+        self.cache: Dict[str, List[str]] = {}
+        self.pad_token_id = None
+
+    @classmethod
+    def from_files(cls, path: str) -> "ByteLevelBPE":
+        with open(os.path.join(path, "vocab.json"), encoding="utf-8") as f:
+            vocab = json.load(f)
+        with open(os.path.join(path, "merges.txt"), encoding="utf-8") as f:
+            lines = [ln.rstrip("\n") for ln in f if ln.strip() and not ln.startswith("#version")]
+        return cls(vocab, [tuple(ln.split(" ")) for ln in lines])
+
+    def __len__(self):
+        return len(self.encoder)
+
+    def _bpe(self, word: str) -> List[str]:
+        if word in self.cache:
+            return self.cache[word]
+        parts = list(word)
+        while len(parts) > 1:
+            best, at = None, -1
+            for i in range(len(parts) - 1):
+                r = self.ranks.get((parts[i], parts[i + 1]))
+                if r is not None and (best is None or r < best):
+                    best, at = r, i
+            if best is None:
+                break
+            a, b = parts[at], parts[at + 1]
+            out, i = [], 0
+            while i < len(parts):                 # merge every occurrence of the best-ranked pair, left to right
+                if i < len(parts) - 1 and parts[i] == a and parts[i + 1] == b:
+                    out.append(a + b)
+                    i += 2
+                else:
+                    out.append(parts[i])
+                    i += 1
+            parts = out
+        self.cache[word] = parts
+        return parts
+
+    def encode(self, text: str) -> List[int]:
+        ids: List[int] = []
+        for piece in self.pat.findall(text):
+            word = "".join(self.b2u[b] for b in piece.encode("utf-8"))
+            ids.extend(self.encoder[t] for t in self._bpe(word))
+        return ids
+
+    def decode(self, ids: Sequence[int]) -> str:
+        text = "".join(self.decoder[int(i)] for i in ids)
+        return bytearray(self.u2b[c] for c in text).decode("utf-8", errors="replace")
+
+
+# ------------------------------------------------------------------------------------------------ prompt composition
+def compose_discrete_prompt_text(entities: Sequence[str]) -> str:
+    """compose_discrete_prompts (P/src/viecap/utils.py:55-74), the string before tokenisation."""
+    if len(entities) == 0:
+        return "There are something in image."
+    return "There are" + "".join(" " + e + "," for e in entities)[:-1] + " in image."
+
+
+def top_k_entities(texts: Sequence[str], probs_row: Sequence[float], top_k: int, threshold: float) -> List[str]:
+    """top_k_categories (P/src/viecap/retrieval_categories.py:97-116) for one image: torch.topk order, cut at the first
+    probability below the threshold."""
+    vals, idx = torch.topk(torch.as_tensor(probs_row), k=top_k, dim=-1)
+    out = []
+    for v, i in zip(vals.tolist(), idx.tolist()):
+        if v < threshold:
+            break
+        out.append(texts[i])
+    return out
+
+
+DEFAULTS = {  # VieCap.defaults (entrypoint.py:61-80)
+    "language_model": "gpt2", "continuous_prompt_length": 10, "clip_project_length": 10, "temperature": 0.01, "top_k": 3,
+    "threshold": 0.2, "disable_all_entities": False, "name_of_entities_text": "vinvl_vgoi_entities", "prompt_ensemble": False,
+    "weight_path": "/raid/datasets/viecap_files/checkpoints/train_coco/coco_prefix-0014.pt", "files_path": "/raid/datasets/viecap_files/",
+    "using_hard_prompt": False, "soft_prompt_first": False, "only_hard_prompt": False, "using_greedy_search": False,
+    "beam_width": 5, "text_prompt": None,
+}
+
+
+def _entity_files(args: Namespace, suffix: str):
+    """get_viecap_texts_embeddings (entrypoint.py:174-223) for the vocabularies kept as a plain list + a pickled tensor."""
+    suffix = suffix.replace("/", "")
+    vocab_dir = os.path.join(args.files_path, "annotations/vocabulary")
+    if not os.path.exists(vocab_dir):
+        raise FileNotFoundError("entity vocabulary directory %r not found (pass viecap.entities_text / viecap.texts_embeddings "
+                                "or point viecap.files_path at the reference's files)" % vocab_dir)
+    if args.name_of_entities_text != "coco_entities":
+        raise NotImplementedError("entity vocabulary %r: only 'coco_entities' (a JSON list + a pickled [K, C] tensor) is read "
+                                  "from files; pass viecap.entities_text / viecap.texts_embeddings for the others" % args.name_of_entities_text)
+    with open(os.path.join(vocab_dir, "coco_categories.json")) as f:
+        ents = json.load(f)
+    if not args.disable_all_entities:
+        ents = [e.lower().strip() for e in ents]
+    else:
+        ents = [e.lower().strip() for e in ents if len(e.split()) == 1]
+    ents.sort()
+    name = "coco_embeddings_%s%s.pickle" % (suffix, "_with_ensemble" if args.prompt_ensemble else "")
+    with open(os.path.join(vocab_dir, name), "rb") as f:
+        emb = pickle.load(f)
+    return ents, torch.as_tensor(emb).float()
+
+
+class VieCapHead:
+    """Mirror of ``VieCap`` (P/src/viecap/entrypoint.py:16): ``forward(image_features, compute_scores)`` -> captions."""
+
+    def __init__(self, args: dict, engine, clip_name: Optional[str]):
+        args_dict = dict(args)
+        for k, v in DEFAULTS.items():
+            args_dict.setdefault(k, v)
+        self.args = a = Namespace(**args_dict)
+        self.engine = engine
+        self.device = engine.device
+        self.clip_hidden_size = args_dict.get("clip_hidden_size") or (640 if "RN" in (clip_name or "") else 512)
+        if "gpt" not in a.language_model:
+            raise NotImplementedError("ViECap with an OPT language model (opt_search): outside the hot-path scope")
+        if not a.using_greedy_search:
+            raise NotImplementedError("ViECap beam search (search.py:193-285): the hot path is the greedy search the shipped "
+                                      "config selects (using_greedy_search: True)")
+        if args_dict.get("entities_text") is not None:
+            self.entities_text = list(args_dict["entities_text"])
+            emb = torch.as_tensor(args_dict["texts_embeddings"]).float()
+        else:
+            self.entities_text, emb = _entity_files(a, args_dict.get("suffix") or (clip_name or ""))
+        if emb.shape != (len(self.entities_text), self.clip_hidden_size):
+            raise ValueError("entity embeddings are %s, expected [%d, %d]" % (tuple(emb.shape), len(self.entities_text), self.clip_hidden_size))
+        tok = args_dict.get("tokenizer")
+        if tok is None:
+            path = args_dict.get("tokenizer_path")
+            if not path:
+                raise FileNotFoundError("viecap.tokenizer_path (a directory with GPT-2's vocab.json and merges.txt) is required: "
+                                        "AutoTokenizer.from_pretrained('gpt2') needs network, which this target does not have")
+            tok = ByteLevelBPE.from_files(path)
+        self.tokenizer = tok
+        engine.viecap_set_entities(emb)
+        # eos ids as greedy_search takes them (search.py:141): the LAST token of "." and of " ."
+        self.eos = [self.tokenizer.encode(e)[-1] for e in (".", " .")]
+
+    def forward(self, image_features: torch.Tensor, compute_scores: bool = False):
+        """entrypoint.py:98-153.  image_features [N, clip_hidden_size] is L2-normalised IN PLACE (line 108)."""
+        a, eng = self.args, self.engine
+        if compute_scores:
+            raise NotImplementedError("ViECap perplexity scores (entrypoint.py:155-172) re-tokenise the captions and run a "
+                                      "teacher-forced language-model pass: not built")
+        pad_id = self.tokenizer.pad_token_id if self.tokenizer.pad_token_id is not None else 0
+        x = image_features
+        if not isinstance(x, torch.Tensor):
+            x = torch.tensor(x, dtype=torch.float)
+        xd = x.to(device=eng.device, dtype=torch.float32).contiguous()
+        cont = eng.viecap_mapping(xd)                                   # normalises xd in place
+        if isinstance(image_features, torch.Tensor) and xd.data_ptr() != image_features.data_ptr():
+            image_features.copy_(xd)
+        N = xd.shape[0]
+        tokens = None
+        if a.using_hard_prompt:
+            probs = eng.viecap_entity_logits(xd, a.temperature).cpu()
+            rows = []
+            for i in range(N):
+                ents = top_k_entities(self.entities_text, probs[i], a.top_k, a.threshold)
+                rows.append(self.tokenizer.encode(compose_discrete_prompt_text(ents)))
+            L = max(len(r) for r in rows)
+            tokens = torch.full((N, L), pad_id, dtype=torch.int32)       # pad_sequence(batch_first=True, padding_value=pad_id)
+            for i, r in enumerate(rows):
+                tokens[i, :len(r)] = torch.tensor(r, dtype=torch.int32)
+            self.last_prompt_tokens = tokens
+        if a.using_hard_prompt and a.only_hard_prompt:
+            raise NotImplementedError("only_hard_prompt (no soft prompt in the sequence)")
+        ids = eng.viecap_decode(cont, tokens, soft_first=bool(a.soft_prompt_first) or tokens is None, steps=64)
+        self.last_ids = ids
+        rows = ids.cpu().tolist()
+        if N == 1:
+            # search.py:172-181: a single caption stops at its first full stop and comes back as a str, not a list
+            r = rows[0]
+            for i, t in enumerate(r):
+                if t in self.eos:
+                    return self.tokenizer.decode(r[:i + 1])
+            return self.tokenizer.decode(r)
+        out = []
+        for r in rows:
+            i = len(r) - 1
+            for j, t in enumerate(r):
+                if t in self.eos:
+                    i = j
+                    break
+            out.append(self.tokenizer.decode(r[:i + 1]))
+        return out
+
+
+def load_viecap_weights(cfg: dict) -> Dict[str, torch.Tensor]:
+    sd = cfg.get("weights")
+    if sd is None:
+        path = cfg.get("weight_path", DEFAULTS["weight_path"])
+        if not os.path.exists(path):
+            raise FileNotFoundError("ViECap checkpoint %r not found (no HuggingFace download on this target)" % (path,))
+        sd = torch.load(path, map_location="cpu")
+    return sd

@@ -147,3 +147,113 @@ def synth_bank(seed: int, rows: int, dim: int = 768) -> torch.Tensor:
 def synth_images(seed: int, batch: int, size: int = 224) -> torch.Tensor:
     g = torch.Generator().manual_seed(seed)
     return torch.randn(batch, 3, size, size, generator=g)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ViECap head (P/src/viecap): seeded stand-ins for the checkpoint, the GPT-2 tokenizer files and the entity vocabulary
+# ---------------------------------------------------------------------------------------------------------------------
+def synth_viecap(seed: int, clip_hidden_size: int = 768, n_layer: int = 12, n_embd: int = 768, vocab: int = 50257,
+                 n_positions: int = 1024, tok_vocab: int = 50257, prompt_len: int = 10, project_len: int = 10,
+                 map_layers: int = 8, std: float = 0.02) -> Dict[str, torch.Tensor]:
+    """State dict shaped like ``ClipCaptionModel.state_dict()`` (P/src/viecap/ClipCap.py:155-200): ``mapping_network.*``
+    (Linear C -> project_len x 768, prefix_const, 8 transformer layers with bias-free q / kv projections and a ratio-2 ReLU
+    MLP) and ``gpt.*`` (GPT2LMHeadModel, GPT2Config() sizes).  Embedding rows >= ``tok_vocab`` are zero (tied head: logit 0),
+    so a random-weight arg-max never leaves the tokenizer's vocabulary."""
+    g = torch.Generator().manual_seed(seed)
+    E = n_embd
+
+    def n(*shape, s=std):
+        return torch.randn(*shape, generator=g) * s
+
+    w: Dict[str, torch.Tensor] = {}
+    w["mapping_network.linear.weight"] = n(project_len * E, clip_hidden_size, s=0.05)
+    w["mapping_network.linear.bias"] = n(project_len * E)
+    w["mapping_network.prefix_const"] = n(prompt_len, E, s=0.5)
+    for l in range(map_layers):
+        p = "mapping_network.transformer.layers.%d." % l
+        w[p + "norm1.weight"] = 0.5 + torch.rand(E, generator=g)
+        w[p + "norm1.bias"] = n(E)
+        w[p + "attn.to_queries.weight"] = n(E, E, s=0.04)
+        w[p + "attn.to_keys_values.weight"] = n(2 * E, E, s=0.04)
+        w[p + "attn.project.weight"] = n(E, E)
+        w[p + "attn.project.bias"] = n(E)
+        w[p + "norm2.weight"] = 0.5 + torch.rand(E, generator=g)
+        w[p + "norm2.bias"] = n(E)
+        w[p + "mlp.fc1.weight"] = n(2 * E, E)
+        w[p + "mlp.fc1.bias"] = n(2 * E)
+        w[p + "mlp.fc2.weight"] = n(E, 2 * E)
+        w[p + "mlp.fc2.bias"] = n(E)
+    wte = n(vocab, E)
+    wte[tok_vocab:] = 0
+    w["gpt.transformer.wte.weight"] = wte
+    w["gpt.transformer.wpe.weight"] = n(n_positions, E)
+    for l in range(n_layer):
+        p = "gpt.transformer.h.%d." % l
+        w[p + "ln_1.weight"] = 0.5 + torch.rand(E, generator=g)
+        w[p + "ln_1.bias"] = n(E)
+        w[p + "attn.c_attn.weight"] = n(E, 3 * E)      # Conv1D: [in, out]
+        w[p + "attn.c_attn.bias"] = n(3 * E)
+        w[p + "attn.c_proj.weight"] = n(E, E)
+        w[p + "attn.c_proj.bias"] = n(E)
+        w[p + "ln_2.weight"] = 0.5 + torch.rand(E, generator=g)
+        w[p + "ln_2.bias"] = n(E)
+        w[p + "mlp.c_fc.weight"] = n(E, 4 * E)
+        w[p + "mlp.c_fc.bias"] = n(4 * E)
+        w[p + "mlp.c_proj.weight"] = n(4 * E, E)
+        w[p + "mlp.c_proj.bias"] = n(E)
+    w["gpt.transformer.ln_f.weight"] = 0.5 + torch.rand(E, generator=g)
+    w["gpt.transformer.ln_f.bias"] = n(E)
+    w["gpt.lm_head.weight"] = wte  # tied
+    return w
+
+
+SYNTH_ENTITIES = ["person", "bicycle", "car", "motorcycle", "airplane", "bus", "train", "truck", "boat", "traffic light",
+                  "fire hydrant", "stop sign", "bench", "bird", "cat", "dog", "horse", "sheep", "cow", "elephant", "bear", "zebra",
+                  "giraffe", "backpack", "umbrella", "handbag", "tie", "suitcase", "frisbee", "skis", "kite", "baseball bat"]
+
+
+def synth_entity_embeddings(seed: int, count: int, dim: int) -> torch.Tensor:
+    return torch.randn(count, dim, generator=torch.Generator().manual_seed(seed))
+
+
+def synth_bpe(seed: int = 0, merges: int = 400):
+    """A small byte-level BPE vocabulary in GPT-2's file format (vocab dict, ranked merges) learnt on the words the ViECap
+    hard prompt is made of ("There are ... in image.", the entity names) plus seeded filler words: the real ``vocab.json`` /
+    ``merges.txt`` are not on this image.  -> (vocab: token -> id, merges: list of pairs); ids 0..255 are the byte tokens."""
+    import random
+    from .viecap import ByteLevelBPE, _bytes_to_unicode
+    import regex
+    rng = random.Random(seed)
+    b2u = _bytes_to_unicode()
+    words = ["There are something in image.", "There are " + ", ".join(SYNTH_ENTITIES) + " in image.", " .", "."]
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    for _ in range(300):
+        words.append(" " + "".join(rng.choice(letters) for _ in range(rng.randint(2, 8))))
+    pat = regex.compile(ByteLevelBPE.PATTERN)
+    corpus = []
+    for t in words:
+        for piece in pat.findall(t):
+            corpus.append(["".join(b2u[b] for b in piece.encode("utf-8"))][0])
+    seqs = [list(w) for w in corpus]
+    vocab = {b2u[b]: b for b in range(256)}
+    merge_list = []
+    for _ in range(merges):
+        counts = {}
+        for sq in seqs:
+            for a, b in zip(sq, sq[1:]):
+                counts[(a, b)] = counts.get((a, b), 0) + 1
+        if not counts:
+            break
+        best = max(sorted(counts), key=lambda p: counts[p])
+        if counts[best] < 2:
+            break
+        merge_list.append(best)
+        vocab[best[0] + best[1]] = len(vocab)
+        for sq in seqs:
+            i = 0
+            while i < len(sq) - 1:
+                if sq[i] == best[0] and sq[i + 1] == best[1]:
+                    sq[i:i + 2] = [best[0] + best[1]]
+                else:
+                    i += 1
+    return vocab, merge_list

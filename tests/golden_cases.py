@@ -207,3 +207,28 @@ def h5_bank_case():
              "", "na\u00efve r\u00e9sum\u00e9 \u2014 d\u00e9j\u00e0 vu", "x" * 300]
     texts = ["%s #%d" % (words[i % len(words)], i) if words[i % len(words)] else "" for i in range(c["rows"])]
     return emb, texts
+
+
+# ---- ViECap head --------------------------------------------------------------------------------
+VIECAP = dict(seed_w=301, seed_ent=302, seed_x=303, seed_bpe=0, C=768, gpt_layers=12, N=6, temperature=0.01, top_k=3, threshold=0.4)
+
+
+def viecap_case():
+    """(weights, tokenizer vocabulary + merges, entity names, entity embeddings, features [6, 768]) of the ViECap fixture:
+    hard prompts of different lengths -- one entity, two entities, a two-word entity, none (the 'something' prompt) -- and
+    plain noise."""
+    from patchioner_amd import weights as W
+    c = VIECAP
+    vocab, merges = W.synth_bpe(c["seed_bpe"])
+    w = W.synth_viecap(c["seed_w"], clip_hidden_size=c["C"], n_layer=c["gpt_layers"], tok_vocab=len(vocab))
+    ents = list(W.SYNTH_ENTITIES)
+    emb = W.synth_entity_embeddings(c["seed_ent"], len(ents), c["C"])
+    e = emb / emb.norm(dim=-1, keepdim=True)
+    x = randn(c["seed_x"], c["N"], c["C"]) * 0.02
+    x[0] += e[3]                                  # one entity
+    x[1] = 3.0 * (1.002 * e[10] + e[20])          # two entities at nearly equal cosine (0.52 / 0.48): both pass the 0.4 threshold,
+                                                  # and their order does not hang on the last bit of a dot product
+    x[2] += e[9]                                  # a two-word entity (longer hard prompt)
+    x[3] += 2.0 * e[15] + 1.9 * e[16]
+    x[4] = e.sum(0)                               # every entity about equally (un)likely: nothing passes -> "something"
+    return w, (vocab, merges), ents, emb, x

@@ -10,13 +10,14 @@ while its top-2 logit margin exceeds what that perturbation moves the logits by.
       history up to there) the oracle's top-2 logit margin on that prefix is at most MARGIN_BOUND.
 
 No test accepts a fraction of wrong captions: every departure has to be explained by (2), one by one.
-MARGIN_BOUND = 0.05 logit units against logits spanning about +-4 (fixtures' median top-2 margin: 0.5): the projection
+MARGIN_BOUND = 0.005 logit units against logits spanning about +-4 (fixtures' median top-2 margin: 0.5): the projection
 softmax at temperature 0.01 multiplies the backbone's 6e-4 relative token error by up to 100 before it reaches the
-decoder prefix, and the largest margin ever observed at a departure is printed by every test (round 2: see DESIGN.md).
+decoder prefix.  Every test prints the largest margin at a departure; over the 770 captions of the round-2 suite there were 2
+departures, at margins of 1.8e-4 and 6.7e-5 (27x below the bound).
 """
 import torch
 
-MARGIN_BOUND = 0.05
+MARGIN_BOUND = 0.005
 
 
 def assert_ids_explained(dec_oracle, gpu_log, ref_ids, label=""):

@@ -1,0 +1,161 @@
+"""ViECap head on the GPU (BASELINE config 5): the C-ABI pieces against the REFERENCE's own outputs
+(tests/golden/viecap.npz, tools/oracle/gen_golden_viecap.py) and the oracle, then the whole head behind
+Patchioner.caption_tokens / forward, and a config-5-shaped run (ViT-L/14, fp16, 16 images, attention-weighted traces).
+
+Bars: mapping network and entity probabilities fp32 round-off (exact-fp32 MFMA, another summation order than ATen);
+hard-prompt token ids exact; greedy ids bit-exact against the oracle on the HIP path's own prompt, and against the
+reference's ids through the parity_helpers bar (identical, or departing at a near-tie only)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from parity_helpers import MARGIN_BOUND
+from patchioner_amd import viecap as V
+from patchioner_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import patchioner_oracle
+    return patchioner_oracle
+
+
+@pytest.fixture(scope="module")
+def case():
+    w, (vocab, merges), ents, emb, x = gc.viecap_case()
+    return w, V.ByteLevelBPE(vocab, merges), ents, emb, x
+
+
+def _viecap_cfg(w, tok, ents, emb, C, **over):
+    c = gc.VIECAP
+    cfg = dict(clip_hidden_size=C, weights=w, tokenizer=tok, entities_text=ents, texts_embeddings=emb, temperature=c["temperature"],
+               top_k=c["top_k"], threshold=c["threshold"], using_hard_prompt=True, soft_prompt_first=True, using_greedy_search=True)
+    cfg.update(over)
+    return cfg
+
+
+def _model(viecap_cfg, dino="dinov2_vitb14_reg", depth=2, **over):
+    from patchioner_amd import Patchioner
+    cfg = {"decap_weights": None, "prefix_size": 768, "linear_talk2dino": False, "support_memory_size": 0, "dino_model": dino,
+           "normalize": False, "resize_dim": 224, "crop_dim": 224, "dino_weights": W.synth_dinov2(91, dino, depth=depth),
+           "max_batch": 16, "max_prefixes": 16, "viecap": viecap_cfg}
+    cfg.update(over)
+    return Patchioner.from_config(cfg, device="cuda")
+
+
+def _explained(orc_margins, got, ref, label):
+    worst = 0.0
+    for r in (got != ref).any(dim=1).nonzero().flatten().tolist():
+        t = int((got[r] != ref[r]).nonzero()[0])
+        m = float(orc_margins[r, t])
+        worst = max(worst, m)
+        assert m <= MARGIN_BOUND, "%s: row %d departs at step %d where the top-2 margin is %.3e" % (label, r, t, m)
+    print("%s: %d / %d id rows identical, largest margin at a departure %.2e" % (label, int((got == ref).all(dim=1).sum()), got.shape[0], worst))
+
+
+def test_viecap_pieces_vs_reference_and_oracle(O, golden, case):
+    g = golden("viecap")
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    w, tok, ents, emb, x = case
+    c = gc.VIECAP
+    m = _model(_viecap_cfg(w, tok, ents, emb, c["C"]))
+    eng = m.engine
+    xd = x.cuda().contiguous()
+    cont = eng.viecap_mapping(xd)
+    np.testing.assert_allclose(xd.cpu().numpy(), (x / x.norm(dim=-1, keepdim=True)).numpy(), rtol=1e-6, atol=1e-7)     # in place
+    np.testing.assert_allclose(cont.cpu().numpy(), g["cont"], rtol=2e-4, atol=5e-5)
+    probs = eng.viecap_entity_logits(xd, c["temperature"])
+    np.testing.assert_allclose(probs.cpu().numpy(), g["entity_probs"], rtol=2e-4, atol=1e-6)
+    # whole head: captions, hard-prompt ids, greedy ids
+    caps = m.caption_tokens(x.clone().cuda())
+    assert np.array_equal(m.viecap.last_prompt_tokens.numpy(), g["prompt_tokens"])
+    ids = m.viecap.last_ids.cpu().long()
+    orc = O.ViECapOracle(w, tok, ents, emb, temperature=c["temperature"], top_k=c["top_k"], threshold=c["threshold"],
+                         using_hard_prompt=True, soft_prompt_first=True)
+    # (1) bit-exact against the oracle's search on the HIP path's OWN prompt (soft prompt from the GPU, same hard prompt)
+    wte = orc.gpt.w["decoder.transformer.wte.weight"]
+    emb_in = torch.cat((cont.cpu(), wte[torch.from_numpy(g["prompt_tokens"]).long()]), dim=1)
+    o_ids, o_margin = [], []
+    logits, past = orc.gpt.gpt2_logits_cached(emb_in)
+    for step in range(64):
+        nxt = logits.argmax(-1, keepdim=True)
+        t2 = logits.topk(2, dim=-1).values
+        o_ids.append(nxt); o_margin.append((t2[:, 0] - t2[:, 1])[:, None])
+        if step < 63:
+            logits, past = orc.gpt.gpt2_logits_cached(wte[nxt], past)
+    o_ids, o_margin = torch.cat(o_ids, 1), torch.cat(o_margin, 1)
+    assert torch.equal(ids, o_ids), "greedy ids differ from the oracle on an identical prompt (min margin %.2e)" % float(o_margin.min())
+    # (2) against the reference's ids (they end at the first full stop): identical or a near-tie
+    ref = torch.from_numpy(g["decoded_ids"]).long()
+    n = (ref >= 0).sum(1)
+    got_cut = ids.clone()
+    for r in range(ids.shape[0]):
+        got_cut[r, n[r]:] = -1
+    _explained(o_margin, got_cut, ref, "ViECap ids vs the reference")
+    if all(torch.equal(got_cut[r], ref[r]) for r in range(ids.shape[0])):
+        assert caps == meta["sentences"]
+    one = m.caption_tokens(x[1:2].clone().cuda())
+    assert isinstance(one, str)                                   # search.py:172-181: a single feature gives a str
+    ids1 = m.viecap.last_ids.cpu().long()
+    want1 = orc.forward(x[1:2].clone())                           # batch 1 may legitimately part from the batch-6 row at a near-tie
+    _explained(orc.last["margins"], ids1, orc.last["ids"], "ViECap single feature vs the oracle")
+    ref1 = torch.from_numpy(g["single_decoded_ids"]).long()[None]
+    cut1 = ids1[:, :ref1.shape[1]]
+    _explained(orc.last["margins"][:, :ref1.shape[1]], cut1, ref1, "ViECap single feature vs the reference")
+    if torch.equal(cut1, ref1):
+        assert one == meta["single_sentence"] == want1
+    with pytest.raises(Exception):
+        m.caption_tokens(x.clone().cuda(), return_n_best_sims=2)
+    with pytest.raises(NotImplementedError):
+        m.caption_tokens(x.clone().cuda(), compute_scores=True)
+
+
+def test_viecap_soft_prompt_only_and_routing_through_forward(O, case):
+    """using_hard_prompt False (the soft prompt alone) against the oracle, and forward(): cls + trace captions come from the head."""
+    w, tok, ents, emb, x = case
+    c = gc.VIECAP
+    m = _model(_viecap_cfg(w, tok, ents, emb, c["C"], using_hard_prompt=False))
+    orc = O.ViECapOracle(w, tok, ents, emb, using_hard_prompt=False)
+    want = orc.forward(x[:3].clone())
+    got = m.caption_tokens(x[:3].clone().cuda())
+    ids = m.viecap.last_ids.cpu().long()
+    _explained(orc.last["margins"], ids, orc.last["ids"], "ViECap soft prompt only vs the oracle")
+    if torch.equal(ids, orc.last["ids"]):
+        assert got == want
+    imgs = W.synth_images(5, 3, 224).cuda()
+    out = m(imgs, get_cls_capt=True, traces=[gc.block_trace(1, 2), gc.block_trace(8, 8), gc.block_trace(12, 0)])
+    assert len(out["cls_capt"]) == 3 and len(out["trace_capts"]) == 3 and all(isinstance(s, str) for s in out["cls_capt"] + out["trace_capts"])
+
+
+def test_config5_shape_vitl14_fp16_attention_weighted_traces(O):
+    """BASELINE config 5 on one GPU's shard: ViT-L/14 (D = 1024, 2 of its 24 blocks here), fp16 operands, 16 images,
+    attention-weighted trace regions into the ViECap head (clip_hidden_size 1024, entity matrix [K, 1024]): the decoder
+    stage bit-exact against the oracle on the HIP path's own region features."""
+    vocab, merges = W.synth_bpe(0)
+    tok = V.ByteLevelBPE(vocab, merges)
+    w = W.synth_viecap(311, clip_hidden_size=1024, n_layer=12, tok_vocab=len(vocab))
+    ents = list(W.SYNTH_ENTITIES)
+    emb = W.synth_entity_embeddings(312, len(ents), 1024)
+    m = _model(_viecap_cfg(w, tok, ents, emb, 1024), dino="dinov2_vitl14_reg", depth=2, vit_dtype="fp16")
+    assert m.embed_dim == 1024
+    imgs = W.synth_images(6, 16, 224).cuda()
+    traces = [gc.block_trace(i % 13, (7 * i) % 13) for i in range(16)]
+    eng = m.engine
+    tokens, qkv = eng.vit_forward(imgs)
+    self_attn, _, _, _ = eng.cls_attention(qkv, tokens)
+    feats = eng.region_reduce(tokens, self_attn * eng.trace_grids(traces).view(16, -1), None, 1.0 / m.num_patch_tokens)
+    out = m(imgs, get_cls_capt=False, traces=traces, use_attention_tracing=True)
+    assert len(out["trace_capts"]) == 16 and all(isinstance(s, str) for s in out["trace_capts"])
+    ids = m.viecap.last_ids.cpu().long()
+    orc = O.ViECapOracle(w, tok, ents, emb, temperature=0.01, top_k=3, threshold=0.4, using_hard_prompt=True, soft_prompt_first=True)
+    want = orc.forward(feats.cpu().clone())
+    assert np.array_equal(m.viecap.last_prompt_tokens.numpy(), orc.last["prompt_tokens"].numpy())
+    _explained(orc.last["margins"], ids, orc.last["ids"], "config 5 shape (ViT-L/14, 16 traces)")
+    if torch.equal(ids, orc.last["ids"]):
+        assert out["trace_capts"] == want

@@ -1,0 +1,82 @@
+"""ViECap head, CPU side: the oracle's restatement (oracle/patchioner_oracle.py: ViECapOracle) against the REFERENCE's own
+pieces run by tools/oracle/gen_golden_viecap.py (tests/golden/viecap.npz), and the host logic of the mirror
+(patchioner_amd/viecap.py: byte-level BPE, prompt text, top-k / threshold, sentence cut)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from oracle import patchioner_oracle as O
+from patchioner_amd import viecap as V
+
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def case():
+    w, (vocab, merges), ents, emb, x = gc.viecap_case()
+    return w, V.ByteLevelBPE(vocab, merges), ents, emb, x
+
+
+def test_oracle_matches_the_reference_pieces(golden, case):
+    g = golden("viecap")
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    w, tok, ents, emb, x = case
+    c = gc.VIECAP
+    orc = O.ViECapOracle(w, tok, ents, emb, temperature=c["temperature"], top_k=c["top_k"], threshold=c["threshold"],
+                         using_hard_prompt=True, soft_prompt_first=True)
+    xin = x.clone()
+    caps = orc.forward(xin)
+    np.testing.assert_allclose(xin.numpy(), (x / x.norm(dim=-1, keepdim=True)).numpy(), rtol=1e-6, atol=1e-7)   # in place
+    np.testing.assert_allclose(orc.last["cont"].numpy(), g["cont"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(orc.last["entity_probs"].numpy(), g["entity_probs"], rtol=1e-4, atol=1e-6)
+    assert np.array_equal(orc.last["prompt_tokens"].numpy(), g["prompt_tokens"])
+    assert [orc.detect(orc.last["entity_probs"][i]) for i in range(x.shape[0])] == meta["detected"]
+    ids, ref = orc.last["ids"].numpy(), g["decoded_ids"]          # the reference's ids end at the first full stop (-1 after it)
+    eos = tok.encode(".")[-1]
+    for r in range(ids.shape[0]):
+        n = int((ref[r] >= 0).sum())
+        assert np.array_equal(ids[r, :n], ref[r, :n]), "row %d, min top-2 margin %.2e" % (r, float(orc.last["margins"][r].min()))
+        assert n == 64 or (ids[r, n - 1] == eos and eos not in ids[r, :n - 1])
+    assert (ref < 0).any(), "the fixture should exercise the cut at the first full stop"
+    assert caps == meta["sentences"]
+    one = orc.forward(x[1:2].clone())
+    assert isinstance(one, str) and one == meta["single_sentence"]
+
+
+def test_mirror_host_logic_matches_the_oracle(case):
+    w, tok, ents, emb, x = case
+    assert V.compose_discrete_prompt_text([]) == O.ViECapOracle.prompt_text([]) == "There are something in image."
+    for e in (["dog"], ["traffic light", "bear"], ["a", "b", "c"]):
+        assert V.compose_discrete_prompt_text(e) == O.ViECapOracle.prompt_text(e)
+    s = "There are person, traffic light in image."
+    ids = tok.encode(s)
+    assert tok.decode(ids) == s and all(0 <= i < len(tok) for i in ids)
+    assert tok.decode(tok.encode("café 山 .")) == "café 山 ."
+    probs = torch.tensor([0.05, 0.45, 0.1, 0.4])
+    assert V.top_k_entities(["a", "b", "c", "d"], probs, 3, 0.4) == ["b", "d"]
+    assert V.top_k_entities(["a", "b", "c", "d"], probs, 3, 0.5) == []
+    assert V.top_k_entities(["a", "b", "c", "d"], probs, 1, 0.0) == ["b"]
+
+
+def test_config_errors_are_loud(case):
+    w, tok, ents, emb, _ = case
+
+    class FakeEngine:
+        device = torch.device("cpu")
+
+        def viecap_set_entities(self, e):
+            self.n = e.shape[0]
+
+    base = dict(clip_hidden_size=768, entities_text=ents, texts_embeddings=emb, tokenizer=tok, using_greedy_search=True)
+    V.VieCapHead(dict(base), FakeEngine(), "ViT-B/16")
+    with pytest.raises(NotImplementedError):
+        V.VieCapHead(dict(base, using_greedy_search=False), FakeEngine(), "ViT-B/16")            # beam search
+    with pytest.raises(NotImplementedError):
+        V.VieCapHead(dict(base, language_model="facebook/opt-1.3b"), FakeEngine(), "ViT-B/16")
+    with pytest.raises(FileNotFoundError):
+        V.VieCapHead({k: v for k, v in base.items() if k != "tokenizer"}, FakeEngine(), "ViT-B/16")
+    with pytest.raises(ValueError):
+        V.VieCapHead(dict(base, texts_embeddings=emb[:, :512]), FakeEngine(), "ViT-B/16")

@@ -62,8 +62,22 @@ def main():
                   "hbm_bytes_per_launch": (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0}
     gemm = [v for k, v in out.items() if "k_vit_gemm" in k]
     tot_l = sum(v["launches"] for v in gemm)
-    summary = {"kernels": out,
+    import datetime
+    summary = {"gemm_kernel": "k_vit_gemm256 / k_vit_gemm",      # bench.py replays these figures only for the kernel named here
+               "collected": datetime.date.today().isoformat(),
+               "kernels": out,
                "vit_gemm_hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches"] for v in gemm) / max(tot_l, 1)}
+    if len(sys.argv) > 6:      # ... <pmc_counters.py json of an SQ pass over the pipelined run>: MFMA utilisation of the GEMM launches
+        pc = json.load(open(sys.argv[6]))
+        busy = act = 0.0
+        for k, v in pc.items():
+            if "k_vit_gemm" in k and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
+                busy += v["SQ_VALU_MFMA_BUSY_CYCLES"] * v["launches"]
+                act += v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0 * v["launches"]
+        if act > 0:
+            summary["mfma_util"] = busy / act
+            summary["mfma_util_source"] = ("replayed: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8) over every "
+                                           "k_vit_gemm* dispatch of a rocprofv3 --pmc pass of this command (%s)" % sys.argv[6])
     if len(sys.argv) > 5:      # ... <out.json> <fetch csv of the pipelined run> <write csv of the pipelined run>
         avg, detail = shared_launch_gemm(sys.argv[4], sys.argv[5], sys.argv[1])
         summary["vit_gemm_hbm_bytes_per_launch_pipelined"] = avg
