@@ -572,7 +572,10 @@ int pio_stream_create(int32_t device, int32_t skip_cus, int32_t n_cus, void** st
 }
 
 int pio_stream_destroy(void* stream) {
-  if (stream) HIP_OK(hipStreamDestroy((hipStream_t)stream));
+  if (stream) {
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));      // nothing of the caller's may still be queued on it
+    HIP_OK(hipStreamDestroy((hipStream_t)stream));
+  }
   return PIO_OK;
 }
 
@@ -636,7 +639,15 @@ int pio_clone_decoder(pio_handle src, pio_handle* out) {
     delete c;
     return rc;
   }
-  HIP_OK(hipDeviceSynchronize());   // the zero-fills above are done before any stream touches the new workspaces
+  {
+    const hipError_t se = hipDeviceSynchronize();   // the zero-fills above are done before any stream touches the new workspaces
+    if (se != hipSuccess) {
+      for (void* p : c->allocs) (void)hipFree(p);
+      (void)hipStreamDestroy(c->capture_stream);
+      delete c;
+      return fail(PIO_ERR_HIP, std::string("pio_clone_decoder: ") + hipGetErrorString(se));
+    }
+  }
   c->has_dec = true;
   c->finalized = true;
   c->parent = src;
@@ -1001,11 +1012,15 @@ int pio_decode_greedy(pio_handle c, const float* prefix, int32_t N, int32_t step
       HIP_OK(hipStreamBeginCapture(c->capture_stream, hipStreamCaptureModeThreadLocal));
       hipError_t le = launch_decode_greedy(a, c->capture_stream);
       hipError_t ce = hipStreamEndCapture(c->capture_stream, &graph);
-      if (le != hipSuccess) return fail(PIO_ERR_HIP, std::string("decode capture: ") + hipGetErrorString(le));
+      if (le != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return fail(PIO_ERR_HIP, std::string("decode capture: ") + hipGetErrorString(le));
+      }
       HIP_OK(ce);
       hipGraphExec_t exec = nullptr;
-      HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-      HIP_OK(hipGraphDestroy(graph));
+      const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      HIP_OK(ie);
       it = c->graphs.emplace(key, exec).first;
     }
     PROF(c, PIO_PROF_DECODE, dec_flops, dec_bytes, s, hipGraphLaunch(it->second, s));

@@ -91,3 +91,46 @@ def sharded_trace_captions(model, imgs: torch.Tensor, traces: Sequence, detokeni
         ids = torch.zeros(0, steps, dtype=torch.int32, device=imgs.device)
     all_ids = all_gather_ids(ids, group)
     return detokenize(all_ids.cpu().tolist())
+
+
+def sharded_box_captions(model, imgs: torch.Tensor, bboxes: torch.Tensor, detokenize, group=None, **fwd) -> List[List[str]]:
+    """Dense / region captioning of a global batch (BASELINE config 4: P/src/model.py:994-1041 behind
+    eval_densecap.py:437-450): every rank receives the same (imgs [B,3,S,S], bboxes [B,NB,4] xywh crop pixels), captions the
+    boxes of its contiguous IMAGE shard with ``model(..., bboxes=...)`` and all ranks return the whole batch's captions as
+    [B][NB], in the original order.  One exchange: the ragged all-gather of the shard's [n_local * NB, steps] token ids.
+    The caller's ``bboxes`` tensor is floor-divided by the patch size in place, as the reference's forward does."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B, NB = bboxes.shape[0], bboxes.shape[1]
+    s, e = shard_bounds(B, world, rank)
+    steps = 30
+    if e > s:
+        model(imgs[s:e], get_cls_capt=False, bboxes=bboxes[s:e], **fwd)       # a view: the in-place // patch_size reaches the caller
+        ids = model.last_ids
+    else:
+        ids = torch.zeros(0, steps, dtype=torch.int32, device=imgs.device)
+    flat = detokenize(all_gather_ids(ids, group).cpu().tolist())
+    if fwd.get("get_controllable_capts"):
+        return flat                           # one caption per image (model.py:1042-1047)
+    return [flat[i * NB:(i + 1) * NB] for i in range(B)]
+
+
+def gather_group_stream(groups, n_groups_local: int, steps: int = 30, device=None, group=None):
+    """The pipelined path's exchange when ranks do NOT produce the same number of decode groups (uneven image shards, a
+    partial last group on some ranks only) and finish them at different times: ``groups`` yields this rank's group ids
+    ([n, steps] int32) as they complete.  All ranks first agree on the number of rounds (one MAX all-reduce), then round k
+    gathers every rank's k-th group -- a rank that has run out contributes zero rows -- so every rank issues the same
+    sequence of collectives whatever the timing.  Yields the gathered [sum_n, steps] ids per round, rank-major."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        for ids in groups:
+            yield ids
+        return
+    t = torch.tensor([n_groups_local], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    rounds = int(t.item())
+    it = iter(groups)
+    for k in range(rounds):
+        ids = next(it, None) if k < n_groups_local else None
+        if ids is None:
+            ids = torch.zeros(0, steps, dtype=torch.int32, device=device)
+        yield all_gather_ids(ids, group)

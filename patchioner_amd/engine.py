@@ -56,8 +56,10 @@ class Engine:
         self._stage_next = 0
 
     def close(self):
+        """Destroys the handle.  An engine that still has live decoder clones is refused by the library (the clones borrow
+        its weights): the handle is kept and the error raised, so that nothing leaks silently."""
         if getattr(self, "h", None) is not None and self.h.value:
-            self.lib.pio_destroy(self.h)
+            check(self.lib.pio_destroy(self.h))
             self.h = ctypes.c_void_p()
 
     def __del__(self):

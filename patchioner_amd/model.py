@@ -283,8 +283,26 @@ class Patchioner(nn.Module):
         return model
 
     def to(self, *args, **kwargs):
-        # weights live in the HIP library on the construction device; moving is a no-op (callers do
-        # model.to(device) with the same device, eval_trace_captioning.py:185)
+        """The weights live in the HIP library on the construction device: ``model.to(<that device>)`` (what the eval drivers
+        do, eval_trace_captioning.py:185) returns self; any other device or a dtype change raises instead of silently
+        leaving the model where it is."""
+        device = kwargs.get("device")
+        dtype = kwargs.get("dtype")
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+            elif isinstance(a, (str, torch.device, int)):
+                device = a
+            elif isinstance(a, torch.Tensor):
+                device, dtype = a.device, a.dtype
+        if dtype is not None and dtype != torch.float32:
+            raise RuntimeError("patchioner_amd: the model's precision is fixed when it is built (vit_dtype); .to(%s) is not supported" % dtype)
+        if device is not None:
+            d = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+            idx = d.index if d.index is not None else (torch.cuda.current_device() if d.type == "cuda" else None)
+            if d.type != "cuda" or idx != self._device.index:
+                raise RuntimeError("patchioner_amd: the model was built on %s and cannot move to %s; build it there with "
+                                   "Patchioner.from_config(config, device=...)" % (self._device, d))
         return self
 
     # ------------------------------------------------------------------------------------------

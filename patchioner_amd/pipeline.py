@@ -97,18 +97,26 @@ class TraceCaptionPipeline:
     def close(self):
         """Release the CU-masked streams (if any).  Everything recorded on them is dropped first: torch's
         ExternalStream wrappers and the events of the group buffers must not outlive the raw streams."""
-        from ._lib import load
+        from ._lib import load, check
         torch.cuda.synchronize()
         for g in self.groups:
             g.staged = []
+            g.pending = []
             g.decoded = torch.cuda.Event()
+            g.ids_dev = None                  # allocator blocks keyed to the streams that are about to go
+        self.last_ids = None
+        # events the engines recorded on those streams (staging rings of trace_grids / preprocess) must not be waited on later
+        for eng in {id(m.engine): m.engine for m in self.stage_models}.values():
+            for slot in eng._stage_ring:
+                slot["event"] = None
         self.stage_streams = [torch.cuda.Stream() for _ in self.stage_models]
         self.decode_streams = [torch.cuda.Stream() for _ in self.decode_engines]
         self.sb = self.decode_streams[0]
         import gc
         gc.collect()
+        torch.cuda.empty_cache()              # cached blocks last used on the raw streams go back to the driver first
         for raw in self._raw_streams:
-            load().pio_stream_destroy(raw)
+            check(load().pio_stream_destroy(raw))
         self._raw_streams = []
         for c in self._own_clones:
             c.close()

@@ -20,8 +20,14 @@ def _free_port():
 class _FakeModel:
     """caption ids are a pure function of the image content, so any sharding must reproduce them"""
 
-    def __call__(self, imgs, get_cls_capt=False, traces=None, **kw):
+    def __call__(self, imgs, get_cls_capt=False, traces=None, bboxes=None, **kw):
         base = (imgs.flatten(1).sum(1) * 7).round().to(torch.int32) % 1000
+        if bboxes is not None:                      # [n, NB, 4] -> one id row per (image, box), image-major
+            bboxes //= 14                           # the reference's in-place floor division (bbox_utils.py:19)
+            off = bboxes.sum(-1).to(torch.int32)
+            ids = (base[:, None] + off).reshape(-1)
+            self.last_ids = ids[:, None] + torch.arange(30, dtype=torch.int32)[None]
+            return {"bbox_capts": None}
         off = torch.tensor([len(t) for t in traces], dtype=torch.int32)
         self.last_ids = (base + off)[:, None] + torch.arange(30, dtype=torch.int32)[None]
         return {"trace_capts": ["x"] * imgs.shape[0]}
@@ -51,6 +57,28 @@ def _worker(rank, world, port, n_imgs, q):
     single = _FakeModel()
     single(imgs, traces=traces)
     assert caps == [tuple(r) for r in single.last_ids.tolist()]
+    # dense boxes (config 4): image shards, nested [B][NB] captions, the caller's boxes floor-divided in place on every rank
+    boxes = (torch.arange(n_imgs * 3 * 4, dtype=torch.float32).reshape(n_imgs, 3, 4) * 5.0) % 200
+    mine, ref = boxes.clone(), boxes.clone()
+    nested = pdist.sharded_box_captions(_FakeModel(), imgs, mine, lambda ids: [tuple(r) for r in ids], gaussian_avg=True)
+    single(imgs, bboxes=ref)
+    want = [tuple(r) for r in single.last_ids.tolist()]
+    assert nested == [want[i * 3:(i + 1) * 3] for i in range(n_imgs)]
+    s0, e0 = pdist.shard_bounds(n_imgs, world, rank)
+    assert torch.equal(mine[s0:e0], ref[s0:e0])
+    # pipelined exchange with UNEVEN group counts and completion times: rank r produces 2 + r groups, rank 1 finishes late
+    import time
+
+    def groups(n):
+        for k in range(n):
+            time.sleep(0.05 * rank * (k + 1))
+            yield torch.full((2 + k + rank, 30), 100 * rank + k, dtype=torch.int32)
+
+    got = list(pdist.gather_group_stream(groups(2 + rank), 2 + rank))
+    assert len(got) == 2 + (world - 1)
+    for k, g in enumerate(got):
+        exp = [torch.full((2 + k + r, 30), 100 * r + k, dtype=torch.int32) for r in range(world) if k < 2 + r]
+        assert torch.equal(g, torch.cat(exp)), k
     if rank == 0:
         q.put(len(caps))
     dist.barrier()

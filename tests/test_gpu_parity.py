@@ -460,7 +460,10 @@ def test_api_surface_and_mutation_quirks():
     m = _make_model(True)
     assert m.patch_size == 14 and m.crop_dim == 224 and m.resize_dim == 224 and m.num_tokens == 261
     assert m.embed_dim == 768 and len(m) > 60_000_000 and next(m.parameters()).device.type == "cuda"
-    assert m.eval() is m and m.to("cuda") is m
+    assert m.eval() is m and m.to("cuda") is m and m.to(torch.device("cuda", torch.cuda.current_device())) is m
+    for bad in ("cpu", torch.float16):
+        with pytest.raises(RuntimeError):
+            m.to(bad)                                                            # never a silent no-op
     x = gc.randn(77, 3, 768).cuda()
     x0 = x.clone()
     caps = m.caption_tokens(x)
