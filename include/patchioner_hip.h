@@ -174,6 +174,15 @@ int pio_mem_project(pio_handle h, float* q_dev, int32_t N, float temperature, in
  * ties: the lower row, like torch.argmax; row indices count the rows KEPT at load, as the reference's do).  1 <= k <= 16. */
 int pio_mem_topk(pio_handle h, float* q, int32_t N, int32_t k, float* best_sims, int64_t* best_rows, pio_stream stream);
 
+/* -- f4 (bank build): ProjectionLayer.project_clip_txt (P/src/talk2dino/talk2dino.py:73-83), the step between CLIP's text
+ *    features and the rows of the memory bank in Im2TxtProjector._build_support_memory (im2txtprojection.py:520-523):
+ *    out = hidden_layer(act(linear_layer(x))) -- or linear_layer(x) alone when w2 is NULL (no hidden layer: the
+ *    activation is then never applied, as in the reference's loop).  Exact fp32.  x [N, in_dim], w1 [out_dim, in_dim],
+ *    w2 [out_dim, out_dim] (torch Linear layout), hidden = [N, out_dim] scratch (needed with w2), out [N, out_dim];
+ *    act: 0 none, 1 relu, 2 tanh, 3 sigmoid (from_config's choices, :44-53); widths are multiples of 32. */
+int pio_text_project(pio_handle h, const float* x, int32_t N, int32_t in_dim, const float* w1, const float* b1, int32_t out_dim,
+                     const float* w2, const float* b2, int32_t act, float* hidden, float* out, pio_stream stream);
+
 /* -- a10: (x - b) @ A_pinv^T (revert_transformation, P/src/embedding_utils.py:17-25). x_dev [N,D] ->
  *    out_dev [N,prefix_size]. */
 int pio_revert_transformation(pio_handle h, const float* x_dev, int32_t N, float* out_dev, pio_stream stream);

@@ -67,6 +67,8 @@ SIGNATURES = {
     "pio_viecap_entity_logits": (c_int32, [c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p]),
     "pio_viecap_decode": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "pio_mem_topk": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "pio_text_project": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
+                                   c_void_p, c_void_p, c_void_p]),
     "pio_revert_transformation": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "pio_decode_greedy": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "pio_profile_enable": (c_int32, [c_void_p, c_int32]),

@@ -969,6 +969,25 @@ int pio_mem_topk(pio_handle c, float* q, int32_t N, int32_t k, float* best_sims,
   return PIO_OK;
 }
 
+int pio_text_project(pio_handle c, const float* x, int32_t N, int32_t in_dim, const float* w1, const float* b1, int32_t out_dim,
+                     const float* w2, const float* b2, int32_t act, float* hidden, float* out, pio_stream stream) {
+  if (!c || !x || !w1 || !b1 || !out) return fail(PIO_ERR_INVALID_ARG, "pio_text_project: null argument");
+  if (N < 1 || in_dim < 32 || in_dim % 32 || out_dim < 32 || out_dim % 32)
+    return fail(PIO_ERR_INVALID_ARG, "pio_text_project: N >= 1 and widths that are multiples of 32");
+  if (act < 0 || act > 3) return fail(PIO_ERR_INVALID_ARG, "pio_text_project: act is 0 none, 1 relu, 2 tanh, 3 sigmoid");
+  if (w2 && (!b2 || !hidden)) return fail(PIO_ERR_INVALID_ARG, "pio_text_project: a hidden layer needs its bias and the [N, out_dim] scratch");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  float* first = w2 ? hidden : out;
+  // linear_layer; the activation precedes every hidden layer (talk2dino.py:77-81), so it is fused here only when one follows
+  HIP_OK(launch_sgemm_tn(x, in_dim, w1, in_dim, b1, 1.0f, first, out_dim, N, out_dim, in_dim, w2 && act == 1, 0, s));
+  if (w2) {
+    if (act >= 2) HIP_OK(launch_activation_f32(first, (size_t)N * out_dim, act, s));
+    HIP_OK(launch_sgemm_tn(first, out_dim, w2, out_dim, b2, 1.0f, out, out_dim, N, out_dim, out_dim, 0, 0, s));
+  }
+  return PIO_OK;
+}
+
 int pio_revert_transformation(pio_handle c, const float* x, int32_t N, float* out, pio_stream stream) {
   if (!c || !x || !out || N < 1) return fail(PIO_ERR_INVALID_ARG, "pio_revert_transformation: bad argument");
   if (!c->has_inv) return fail(PIO_ERR_NOT_READY, "pio_revert_transformation: talk2dino.A_pinv / talk2dino.b not loaded");

@@ -170,6 +170,7 @@ hipError_t launch_viecap_mapping(const ViecapMapArgs& a, hipStream_t s);
 // C = alpha * A W^T (+ bias) (ReLU) (+= C): exact fp32, any M, N; K % 32 == 0
 hipError_t launch_sgemm_tn(const float* A, int lda, const float* W, int ldw, const float* bias, float alpha, float* C, int ldc,
                            int M, int N, int K, int relu, int resid, hipStream_t s);
+hipError_t launch_activation_f32(float* y, size_t n, int act, hipStream_t s);     // 2 tanh, 3 sigmoid, in place
 hipError_t launch_build_prompt(const float* cont, const int32_t* tokens, const float* wte, int N, int Lc, int Lt, int E, int V,
                                int soft_first, float* prompt, hipStream_t s);
 hipError_t launch_l2norm_rows(float* x, int N, int D, hipStream_t s);

@@ -97,6 +97,20 @@ hipError_t launch_sgemm_tn(const float* A, int lda, const float* W, int ldw, con
   return hipGetLastError();
 }
 
+// y = act(y) in place: 2 = tanh, 3 = sigmoid (the activations ProjectionLayer.from_config offers besides ReLU, talk2dino.py:44-53)
+__global__ __launch_bounds__(256) void k_activation_f32(float* y, size_t n, int act) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = y[i];
+  y[i] = act == 2 ? tanhf(v) : 1.0f / (1.0f + expf(-v));
+}
+
+hipError_t launch_activation_f32(float* y, size_t n, int act, hipStream_t s) {
+  if (act != 2 && act != 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_activation_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, n, act);
+  return hipGetLastError();
+}
+
 // rows of x [M][D] -> LayerNorm (biased variance, eps inside the root: torch.nn.LayerNorm) -> y [M][D], one wave per row
 __global__ __launch_bounds__(256) void k_layernorm_f32(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                        float eps, int M, int D, float* y) {

@@ -329,6 +329,27 @@ class Engine:
             check(self.lib.pio_mem_topk(self.h, ptr(q[s:e]), e - s, int(k), ptr(sims[s:e]), ptr(rows[s:e]), _stream()))
         return sims, rows
 
+    ACTS = {None: 0, "none": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
+
+    def text_project(self, x: torch.Tensor, w1, b1, w2=None, b2=None, act="tanh") -> torch.Tensor:
+        """ProjectionLayer.project_clip_txt (P/src/talk2dino/talk2dino.py:73-83): x [N, in] CLIP text features ->
+        hidden_layer(act(linear_layer(x))) [N, out] (linear_layer alone without w2), exact fp32 on the device."""
+        x, w1, b1 = self._dev(x), self._dev(w1), self._dev(b1)
+        N, out_dim = x.shape[0], w1.shape[0]
+        if w1.shape[1] != x.shape[1] or b1.shape != (out_dim,):
+            raise PioError(_lib.PIO_ERR_SHAPE, "linear_layer %s does not take %d-wide features" % (tuple(w1.shape), x.shape[1]))
+        out = torch.empty(N, out_dim, device=self.device, dtype=torch.float32)
+        hid = None
+        if w2 is not None:
+            w2, b2 = self._dev(w2), self._dev(b2)
+            if w2.shape != (out_dim, out_dim) or b2.shape != (out_dim,):
+                raise PioError(_lib.PIO_ERR_SHAPE, "hidden layer %s is not [%d, %d]" % (tuple(w2.shape), out_dim, out_dim))
+            hid = torch.empty_like(out)
+        check(self.lib.pio_text_project(self.h, ptr(x), N, x.shape[1], ptr(w1), ptr(b1), out_dim, ptr(w2) if w2 is not None else None,
+                                        ptr(b2) if w2 is not None else None, self.ACTS[act], ptr(hid) if hid is not None else None,
+                                        ptr(out), _stream()))
+        return out
+
     def revert_transformation(self, x: torch.Tensor) -> torch.Tensor:
         x = self._dev(x)
         out = torch.empty(x.shape[0], self.prefix_size, device=self.device, dtype=torch.float32)

@@ -1,4 +1,4 @@
-"""A dependency-free reader for the memory-bank files of the reference (HDF5 written by h5py with its defaults).
+"""A dependency-free reader AND writer for the memory-bank files of the reference (HDF5 as h5py writes it by default).
 
 ``Im2TxtProjector._build_support_memory`` (P/src/decap/im2txtprojection/im2txtprojection.py:543-555) creates, in the
 root group, ``<name>-embeddings`` = float32 [M, D] and ``<name>-text`` = [M] variable-length UTF-8 strings
@@ -8,6 +8,10 @@ file format (version-0/1 superblock, old-style groups = v1 B-tree + local heap +
 with continuation blocks, dataspace / datatype / data-layout messages, contiguous or compact storage, global heap
 collections for the variable-length strings).  Anything else (chunked / filtered datasets, new-style groups, superblock
 2+) raises ``NotImplementedError`` with the reason, never a silent wrong read.
+
+``write_bank`` is the other direction (the tail of ``_build_support_memory``, :543-555): the same two datasets in the same
+layout, laid out as the library itself lays out a fresh file (version-0 superblock, one symbol node, contiguous data, global
+heap collections for the strings), so that h5py / libhdf5 -- and therefore the reference -- open what it writes.
 
 Format reference: the public "HDF5 File Format Specification Version 2.0/3.0" (III.A superblock, III.A.1 B-trees, III.C
 symbol-table nodes, III.D local heaps, III.E global heaps, IV.A object headers and messages).
@@ -258,3 +262,128 @@ def dataset_names(path: str) -> List[str]:
         return sorted(_group_entries(fh, btree, _local_heap(fh, heap_addr)))
     finally:
         fh.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# writer
+
+
+def _pad8(b: bytes) -> bytes:
+    return b + b"\0" * (-len(b) % 8)
+
+
+def _msg(mtype: int, data: bytes) -> bytes:
+    data = _pad8(data)
+    return struct.pack("<HHB3x", mtype, len(data), 0) + data
+
+
+def _ohdr_v1(msgs: List[bytes]) -> bytes:
+    body = b"".join(msgs)
+    return struct.pack("<BxHII4x", 1, len(msgs), 1, len(body)) + body
+
+
+_F32LE = bytes.fromhex("11201f00" "04000000" "0000" "2000" "17" "08" "00" "17" "7f000000")
+# variable-length UTF-8 string, null-terminated, over a 1-byte base element: the bytes libhdf5 emits for
+# H5Tcopy(H5T_C_S1) + H5Tset_size(H5T_VARIABLE) + H5Tset_cset(UTF8), which is what h5py.string_dtype('utf-8') is
+_VLEN_UTF8 = bytes.fromhex("19010100" "10000000" "10000000" "01000000" "00000800")
+GCOL_MAX_OBJECTS = 8192          # object indices are 16 bits; collections stay around a megabyte
+GCOL_MIN_SIZE = 4096
+
+
+def _dataset_header(shape, dtype_msg: bytes, fill: bytes, addr: int, nbytes: int) -> bytes:
+    rank = len(shape)
+    space = struct.pack("<BBB5x", 1, rank, 1) + b"".join(struct.pack("<Q", int(d)) for d in shape) * 2     # dims, max dims
+    layout = struct.pack("<BBQQ", 3, 1, addr, nbytes)
+    return _ohdr_v1([_msg(0x0001, space), _msg(0x0003, dtype_msg), _msg(0x0005, fill), _msg(0x0008, layout)])
+
+
+def write_bank(path: str, name: str, embeddings: np.ndarray, texts) -> None:
+    """``<name>-embeddings`` float32 [M, D] and ``<name>-text`` [M] variable-length UTF-8 strings in the root group of a new
+    HDF5 file -- the file ``Im2TxtProjector._build_support_memory`` leaves behind (im2txtprojection.py:543-555) and
+    ``_load_support_memory`` (:387-407) / ``read_datasets`` read back."""
+    emb = np.ascontiguousarray(embeddings, dtype="<f4")
+    if emb.ndim != 2:
+        raise ValueError("embeddings must be [M, D]")
+    enc = [t if isinstance(t, bytes) else str(t).encode("utf-8") for t in texts]
+    if len(enc) != emb.shape[0]:
+        raise ValueError("len(texts) = %d != len(embeddings) = %d" % (len(enc), emb.shape[0]))   # the reference's assert (:537)
+    names = sorted([("%s-embeddings" % name).encode(), ("%s-text" % name).encode()])
+    e_name, t_name = ("%s-embeddings" % name).encode(), ("%s-text" % name).encode()
+
+    # local heap data: the empty name at 0, then the link names, then one free block
+    heap = bytearray(8)
+    name_off = {}
+    for n in names:
+        name_off[n] = len(heap)
+        heap += _pad8(n + b"\0")
+    free_at = len(heap)
+    heap += struct.pack("<QQ", 1, 32) + b"\0" * 16                  # next = 1 (end of list), size of this block
+
+    K_LEAF, K_NODE = 4, 16
+    btree_size = 24 + (2 * K_NODE + 1) * 8 + 2 * K_NODE * 8
+    snod_size = 8 + 2 * K_LEAF * 40
+    hdr_size = 16 + 4 * 8 + 40 + 24 + 24 + 24                     # v1 prefix, dataspace (rank<=2 padded below), type, fill, layout
+
+    a_root = 96
+    root_hdr_len = 16 + 8 + 16
+    a_btree = a_root + root_hdr_len
+    a_heap = a_btree + btree_size
+    a_heapdata = a_heap + 32
+    a_snod = a_heapdata + len(heap)
+    a_e_hdr = a_snod + snod_size
+    e_hdr = _dataset_header(emb.shape, _F32LE, bytes.fromhex("0202020100000000"), 0, 0)
+    a_t_hdr = a_e_hdr + len(e_hdr)
+    t_hdr = _dataset_header((len(enc),), _VLEN_UTF8, bytes.fromhex("0202000100000000"), 0, 0)
+    a_e_data = (a_t_hdr + len(t_hdr) + 7) // 8 * 8
+    a_t_data = a_e_data + emb.nbytes
+    a_gcol = a_t_data + 16 * len(enc)
+    del hdr_size
+
+    # global heap collections for the strings + the 16-byte references that point into them
+    refs = bytearray(16 * len(enc))
+    colls: List[bytes] = []
+    addr = a_gcol
+    i = 0
+    while i < len(enc):
+        body = bytearray()
+        idx = 1
+        while i < len(enc) and idx <= GCOL_MAX_OBJECTS:
+            b = enc[i]
+            if b:                                                   # an empty string is the null reference, as libhdf5 writes it
+                struct.pack_into("<IQI", refs, 16 * i, len(b), addr, idx)
+                body += struct.pack("<HH4xQ", idx, 1, len(b)) + _pad8(b)
+                idx += 1
+            i += 1
+        size = 16 + len(body)
+        total = max(GCOL_MIN_SIZE, size + 16)
+        body += struct.pack("<HH4xQ", 0, 0, total - size) + b"\0" * (total - size - 16)      # object 0: the free space
+        colls.append(b"GCOL" + struct.pack("<B3xQ", 1, total) + bytes(body))
+        addr += total
+    eof = addr
+
+    e_hdr = _dataset_header(emb.shape, _F32LE, bytes.fromhex("0202020100000000"), a_e_data, emb.nbytes)
+    t_hdr = _dataset_header((len(enc),), _VLEN_UTF8, bytes.fromhex("0202000100000000"), a_t_data, 16 * len(enc))
+
+    sb = SIGNATURE + struct.pack("<BBBBBBBxHHI", 0, 0, 0, 0, 0, 8, 8, K_LEAF, K_NODE, 0)
+    sb += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
+    sb += struct.pack("<QQI4xQQ", 0, a_root, 1, a_btree, a_heap)    # root entry: cached B-tree / heap addresses
+    assert len(sb) == 96
+    root = _ohdr_v1([_msg(0x0011, struct.pack("<QQ", a_btree, a_heap))])
+    assert len(root) == root_hdr_len
+    btree = b"TREE" + struct.pack("<BBHQQ", 0, 0, 1, UNDEF, UNDEF) + struct.pack("<QQQ", 0, a_snod, name_off[names[-1]])
+    btree += b"\0" * (btree_size - len(btree))
+    lheap = b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap), free_at, a_heapdata)
+    hdr_of = {e_name: a_e_hdr, t_name: a_t_hdr}
+    snod = b"SNOD" + struct.pack("<BxH", 1, len(names))
+    for n in names:
+        snod += struct.pack("<QQI4x16x", name_off[n], hdr_of[n], 0)
+    snod += b"\0" * (snod_size - len(snod))
+
+    with open(path, "wb") as f:
+        f.write(sb + root + btree + lheap + bytes(heap) + snod + e_hdr + t_hdr)
+        f.write(b"\0" * (a_e_data - f.tell()))
+        emb.tofile(f)
+        f.write(bytes(refs))
+        for c in colls:
+            f.write(c)
+        assert f.tell() == eof

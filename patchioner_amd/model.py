@@ -8,7 +8,7 @@ path (constructing the model without a GPU or without the built library raises).
 
 Scope: the DINOv2(+registers) backbone with the DeCap / CapDec decoder head.  The other
 backbones and heads of the reference (ProxyCLIP, RegionCLIP, INViTE, DenseClip, AlphaClip, OpenCLIP, timm
-CLIP, DINO.txt, ViECap, MeaCap, ClipCap) raise ``NotImplementedError`` at construction.
+CLIP, DINO.txt, MeaCap, ClipCap) raise ``NotImplementedError`` at construction.
 
 Build-specific config keys (there is no network on the target, so nothing is fetched from torch.hub / HF):
   dino_weights     path (.pt/.pth state dict) or dict of the DINOv2 backbone weights

@@ -61,6 +61,7 @@ hipError_t launch_mem_project(const ProjectArgs&, hipStream_t) { return hipSucce
 hipError_t launch_mem_topk(const float*, const float*, int64_t, int, float*, int, int, float*, float*, int64_t*, hipStream_t) { return hipSuccess; }
 hipError_t launch_row_inv_norm(const float*, int64_t M, int, float* inv, hipStream_t) { for (int64_t i = 0; i < M; ++i) inv[i] = 1.f; return hipSuccess; }
 hipError_t launch_l2norm_rows(float*, int, int, hipStream_t) { return hipSuccess; }
+hipError_t launch_activation_f32(float*, size_t, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_revert(const float*, const float*, const float*, int, int, int, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_decode_greedy(const DecoderArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_decode_prompted(const DecoderArgs&, const float*, int, hipStream_t) { return hipSuccess; }

@@ -29,7 +29,7 @@ def assert_ids_explained(dec_oracle, gpu_log, ref_ids, label=""):
     R = torch.cat([torch.as_tensor(r).long().reshape(-1, G.shape[1]) for r in ref_ids])
     assert G.shape == R.shape, (label, G.shape, R.shape)
     keep = torch.isfinite(P).all(dim=1)          # NaN prefixes (dummy boxes): the reference decodes garbage from NaN as well
-    o_ids, _, o_margin = dec_oracle.decode_ids(P[keep])
+    o_ids, _, o_margin = dec_oracle.decode_ids(P[keep], cached=True)     # same sums, keys/values kept (test_oracle_golden pins it)
     assert torch.equal(G[keep], o_ids), "%s: decoder ids differ from the oracle on identical prefixes" % label
     Gk, Rk = G[keep], R[keep]
     worst, departed = 0.0, 0

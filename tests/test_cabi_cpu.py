@@ -86,7 +86,9 @@ def test_out_of_scope_options_raise():
     from patchioner_amd import Patchioner
     base = {"prefix_size": 768, "support_memory_size": 0, "synthetic_seed": 0}
     with pytest.raises(NotImplementedError):
-        Patchioner.from_config(dict(base, dino_model="dinov2_vitb14_reg", viecap={"x": 1}), device="cuda")
+        Patchioner.from_config(dict(base, dino_model="dinov2_vitb14_reg", viecap={"meacap": True}), device="cuda")
+    with pytest.raises(NotImplementedError):
+        Patchioner.from_config(dict(base, dino_model="dinov2_vitb14_reg", clipcap={"x": 1}), device="cuda")
     with pytest.raises(ValueError):
         Patchioner.from_config(dict(base, dino_model="vit_base_patch16_clip_224.openai"), device="cuda")
     with pytest.raises(Exception, match="projection_type"):

@@ -64,3 +64,89 @@ def test_loud_failures(tmp_path):
     t.write_bytes(bytes(raw[:4096]).replace(b"\x02", b"\x00", 0))
     with pytest.raises((ValueError, NotImplementedError)):
         h5lite.read_datasets(str(t))
+
+
+def _libhdf5():
+    import ctypes
+    for cand in ("/opt/conda/lib/libhdf5.so.103", "/opt/conda/lib/libhdf5.so", "libhdf5.so", "libhdf5_serial.so"):
+        try:
+            return ctypes.CDLL(cand)
+        except OSError:
+            continue
+    return None
+
+
+def test_writer_round_trip_and_many_heap_collections(tmp_path):
+    """h5lite.write_bank -> h5lite.read_datasets: ragged / empty / non-ASCII captions, zero rows, and more strings than one
+    global-heap collection holds (16-bit object indices)."""
+    g = np.random.default_rng(5)
+    M = h5lite.GCOL_MAX_OBJECTS * 2 + 77
+    emb = g.standard_normal((M, 8)).astype(np.float32)
+    emb[[0, 5]] = 0
+    texts = ["caption %d %s" % (i, "x" * (i % 37)) for i in range(M)]
+    texts[3], texts[4] = "", "un café à la crème ☕"
+    p = str(tmp_path / "big.h5")
+    h5lite.write_bank(p, "vg_captions", emb, texts)
+    d = h5lite.read_datasets(p)
+    assert sorted(d) == ["vg_captions-embeddings", "vg_captions-text"]
+    assert np.array_equal(d["vg_captions-embeddings"], emb)
+    assert [b.decode("utf-8") for b in d["vg_captions-text"]] == texts
+    with pytest.raises(ValueError):
+        h5lite.write_bank(p, "x", emb, texts[:-1])
+
+
+def test_written_bank_is_read_by_the_hdf5_library(tmp_path):
+    """the file h5lite.write_bank produces, opened with libhdf5 itself (the library under h5py, i.e. under the reference's
+    ``h5py.File(path)[name][:]``, im2txtprojection.py:398-401): both datasets, values and strings identical.  Skipped where
+    no libhdf5 exists (the GPU box); the build container has one."""
+    import ctypes
+    h = _libhdf5()
+    if h is None:
+        pytest.skip("no libhdf5 on this machine")
+    emb, texts = gc.h5_bank_case()
+    p = str(tmp_path / "w.h5")
+    h5lite.write_bank(p, "coco", emb, texts)
+    hid = ctypes.c_int64
+    h.H5open()
+    for fn, res, args in (("H5Fopen", hid, [ctypes.c_char_p, ctypes.c_uint, hid]), ("H5Dopen2", hid, [hid, ctypes.c_char_p, hid]),
+                          ("H5Dread", ctypes.c_int, [hid, hid, hid, hid, hid, ctypes.c_void_p]), ("H5Dget_space", hid, [hid]),
+                          ("H5Sget_simple_extent_dims", ctypes.c_int, [hid, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p]),
+                          ("H5Tcopy", hid, [hid]), ("H5Tset_size", ctypes.c_int, [hid, ctypes.c_size_t]),
+                          ("H5Tset_cset", ctypes.c_int, [hid, ctypes.c_int]), ("H5Dclose", ctypes.c_int, [hid]),
+                          ("H5Fclose", ctypes.c_int, [hid]), ("H5Dget_type", hid, [hid]), ("H5Tis_variable_str", ctypes.c_int, [hid]),
+                          ("H5Tget_cset", ctypes.c_int, [hid])):
+        getattr(h, fn).restype, getattr(h, fn).argtypes = res, args
+    f = h.H5Fopen(p.encode(), 0, 0)
+    assert f >= 0, "libhdf5 refuses the file"
+    d = h.H5Dopen2(f, b"coco-embeddings", 0)
+    assert d >= 0
+    dims = (ctypes.c_uint64 * 2)()
+    assert h.H5Sget_simple_extent_dims(h.H5Dget_space(d), dims, None) == 2 and tuple(dims) == emb.shape
+    got = np.empty_like(emb)
+    f32 = hid.in_dll(h, "H5T_NATIVE_FLOAT_g").value
+    assert h.H5Dread(d, f32, 0, 0, 0, got.ctypes.data_as(ctypes.c_void_p)) >= 0 and np.array_equal(got, emb)
+    h.H5Dclose(d)
+    d = h.H5Dopen2(f, b"coco-text", 0)
+    assert d >= 0
+    ft = h.H5Dget_type(d)
+    assert h.H5Tis_variable_str(ft) > 0 and h.H5Tget_cset(ft) == 1           # variable-length, UTF-8: h5py.string_dtype('utf-8')
+    st = h.H5Tcopy(hid.in_dll(h, "H5T_C_S1_g").value)
+    h.H5Tset_size(st, ctypes.c_size_t(-1).value)
+    h.H5Tset_cset(st, 1)
+    ptrs = (ctypes.c_char_p * len(texts))()
+    assert h.H5Dread(d, st, 0, 0, 0, ctypes.cast(ptrs, ctypes.c_void_p)) >= 0
+    assert [(x or b"").decode("utf-8") for x in ptrs] == texts
+    h.H5Dclose(d)
+    assert h.H5Fclose(f) >= 0
+
+
+def test_bank_file_names_follow_the_reference_rule():
+    """im2txtprojection.py:100-170, :234, :289-299 -- the names the released banks carry"""
+    from patchioner_amd.bank import memory_bank_filename
+    assert memory_bank_filename("coco_captions", None, 591753) == ("coco_captions_text_embeddings-B16-ViT-B.16-591753.h5", "coco_captions")
+    assert memory_bank_filename("vg_captions", "ViT-B/16", 500000, linear_talk2dino=True)[0] == \
+        "vg_captions_text_embeddings-B16-linear-ViT-B.16-500000.h5"
+    assert memory_bank_filename("coco_captions", None, 1000, use_talk2dino=False)[0] == "clip-coco_captions_text_embeddings-ViT-B.32-1000.h5"
+    assert memory_bank_filename("my_bank", "ViT-L/14", 10, talk2dino_attn_type="cls")[0] == "my_bank_text_embeddings_cls-B16-ViT-L.14-10.h5"
+    assert memory_bank_filename("coco_captions", "ViT-B/32", 7, use_talk2dino=False, use_open_clip=True)[0] == \
+        "clip-coco_captions_text_embeddings-open_clip-ViT-B.32-7.h5"
