@@ -27,6 +27,14 @@ from typing import Iterable, Iterator, List, Optional, Sequence, Tuple
 import torch
 
 
+# CU-masked streams (pio_stream_create) live for the life of the PROCESS, like torch's own pooled streams: torch's caching
+# allocators -- device blocks with record_stream'ed uses, pinned host blocks used by a non-blocking copy -- keep the raw
+# stream handle in the block and record an event on it when the block is freed, however much later; a stream destroyed in
+# between is a dangling handle there (round 1's host segfault in a create / destroy loop: amd::Marker::submit under
+# CachingHostAllocatorImpl::free, tests/test_gpu_zz_lifecycle.py).  close() returns the streams to this pool instead.
+_CU_STREAM_POOL: dict = {}             # (device index, first CU, CUs) -> [raw stream handles not in use]
+
+
 class _Group:
     def __init__(self, cap: int, dim: int, steps: int, device):
         self.prefix = torch.empty(cap, dim, device=device, dtype=torch.float32)
@@ -87,17 +95,21 @@ class TraceCaptionPipeline:
             return torch.cuda.Stream()
         from ._lib import load, check
         import ctypes
-        raw = ctypes.c_void_p()
         total = torch.cuda.get_device_properties(self.eng.device).multi_processor_count
         skip = max(0, total - int(n_cus)) if from_top else 0
-        check(load().pio_stream_create(self.eng.device.index or 0, skip, int(n_cus), ctypes.byref(raw)))
-        self._raw_streams.append(raw)
+        key = (self.eng.device.index or 0, skip, int(n_cus))
+        free = _CU_STREAM_POOL.setdefault(key, [])
+        if free:
+            raw = free.pop()
+        else:
+            raw = ctypes.c_void_p()
+            check(load().pio_stream_create(key[0], skip, int(n_cus), ctypes.byref(raw)))
+        self._raw_streams.append((key, raw))
         return torch.cuda.ExternalStream(raw.value, device=self.eng.device)
 
     def close(self):
-        """Release the CU-masked streams (if any).  Everything recorded on them is dropped first: torch's
-        ExternalStream wrappers and the events of the group buffers must not outlive the raw streams."""
-        from ._lib import load, check
+        """Drain, drop everything recorded on this pipeline's streams, hand the CU-masked ones back to the process-wide pool
+        (they are never destroyed, see _CU_STREAM_POOL) and close the decoder clones made here."""
         torch.cuda.synchronize()
         for g in self.groups:
             g.staged = []
@@ -112,11 +124,8 @@ class TraceCaptionPipeline:
         self.stage_streams = [torch.cuda.Stream() for _ in self.stage_models]
         self.decode_streams = [torch.cuda.Stream() for _ in self.decode_engines]
         self.sb = self.decode_streams[0]
-        import gc
-        gc.collect()
-        torch.cuda.empty_cache()              # cached blocks last used on the raw streams go back to the driver first
-        for raw in self._raw_streams:
-            check(load().pio_stream_destroy(raw))
+        for key, raw in self._raw_streams:
+            _CU_STREAM_POOL[key].append(raw)
         self._raw_streams = []
         for c in self._own_clones:
             c.close()
