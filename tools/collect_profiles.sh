@@ -34,3 +34,7 @@ cp $(find $out/sync -name "*kernel_stats.csv" | head -1) profiles/${round}_kerne
 cp $(find $out/pipe -name "*kernel_stats.csv" | head -1) profiles/${round}_kernel_stats_pipelined.csv
 python3 tools/trace_by_grid.py $(find $out/pipe -name "*kernel_trace.csv" | head -1) k_vit_gemm profiles/${round}_vit_gemm_pipelined_by_grid.csv
 tail -1 $out/bench_line.json > profiles/${round}_bench_line.json
+# gpurun merges at most 64 MiB of gpurun_out/ back: keep the summaries (and the logs), drop the raw traces
+mkdir -p $R/gpurun_out/profiles_out
+cp profiles/${round}_* profiles/traffic.json $R/gpurun_out/profiles_out/
+find $out -name "*.csv" -delete

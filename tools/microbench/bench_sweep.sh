@@ -1,0 +1,26 @@
+#!/bin/bash
+# A/B of bench.py settings on one box (values differ by up to 12 % between boxes, so compare within one call):
+#   tools/microbench/bench_sweep.sh  ->  gpurun_out/sweep.log  (one line per setting: captions/s, median ms per group)
+cd "$(dirname "$0")/../.."
+mkdir -p gpurun_out
+export PIO_BENCH_STAT_GROUPS=24 PIO_BENCH_SYNC_STEPS=4
+run() {   # label, env assignments..., -- bench args...
+  local label=$1; shift
+  local envs=()
+  while [ "$1" != "--" ]; do envs+=("$1"); shift; done
+  shift
+  env "${envs[@]}" timeout -k 10 240 python3 bench.py --no-cpu-baseline "$@" 2> gpurun_out/sweep_err.log | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('%-34s value %7.0f  group median %.2f ms p95 %.2f  gemm %.1f us frac %.3f' % ('$label', d['value'], d['pipelined_groups']['ms_per_group']['median'], d['pipelined_groups']['ms_per_group']['p95'], d['roofline']['avg_launch_us'], d['roofline']['frac']))" >> gpurun_out/sweep.log || return 1
+}
+: > gpurun_out/sweep.log
+run "default" -- &&
+run "old gemm" PIO_GEMM256_MIN_TILES=0 -- &&
+run "decodes 4" -- --decode-streams 4 &&
+run "decodes 5" -- --decode-streams 5 &&
+run "decodes 6" -- --decode-streams 6 &&
+run "old gemm, decodes 5" PIO_GEMM256_MIN_TILES=0 -- --decode-streams 5 &&
+run "vit-batches 2" -- --vit-batches 2 &&
+run "256 only for wide (min tiles 250)" PIO_GEMM256_MIN_TILES=250 --
+cat gpurun_out/sweep.log
