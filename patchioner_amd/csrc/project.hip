@@ -41,6 +41,8 @@ __device__ __forceinline__ float4 ld_stream4(const float* p) {
 }
 
 
+typedef __attribute__((address_space(3))) void* pr_lds_ptr_t;
+
 static constexpr int PR_ROWS = 16;   // bank rows per tile
 static constexpr int PR_Q = 16;      // queries per pass
 
@@ -258,6 +260,289 @@ __global__ __launch_bounds__(256 * NQG, NQG == 1 ? 2 : 1) void k_project(const f
   }
 }
 
+// x combined with the lanes 16 / 32 away, without the LDS crossbar (ds_bpermute, ~130 cycles on a serial chain): gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange rows / halves between two registers; fed (x, x) they return (own-or-partner,
+// partner-or-own), and max / + are commutative, so the result is bit-identical to x op __shfl_xor(x, 16 | 32).
+__device__ __forceinline__ float xor16_max(float x) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor16_add(float x) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_add(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// ---- round 2: the same pass, software-pipelined -------------------------------------------------------------------
+// k_project spends a 16-row tile as  [GEMM1 -> partial S to LDS] barrier [sum, soft-max, GEMM2] barrier [registers -> LDS]
+// barrier: three barriers, a register-staged single buffer, and the MFMA pipe idle around each of them (PMC: 39-49 % busy;
+// 0.83 ms per 32-query pass against 0.37 ms of fp32 MFMA issue).  k_project2 keeps every arithmetic operation and its order
+// -- the outputs are bit-identical, tests/test_gpu_parity.py compares the two -- and changes the plumbing:
+//   * two tile buffers filled by LDS-DMA (global_load_lds, 16 B per lane, non-temporal), no staging registers, no store phase;
+//   * iteration t = GEMM2(t) | wait own DMA of tile t+1, barrier A (tile t free, tile t+1 complete) | DMA(t+2) into tile t's
+//     buffer | GEMM1(t+1) -> partial S | barrier B | sum + soft-max(t+1).  Two barriers per tile, the load of tile t+2 has a
+//     whole iteration to land, GEMM2(t) / GEMM1(t+1) issue back to back (96 MFMAs per wave);
+//   * the rescale of the accumulators (4 lane exchanges + D/16 multiplies) is skipped while no query's running maximum moved
+//     (multiplying by exp(0) = 1 is the identity, so skipping it changes no bit); the row-sum exchanges of the soft-max wait
+//     until GEMM2's MFMAs have been issued; inv_norm of tile t+1 is fetched under GEMM2(t).
+// Measured (one MI355X, 591 753 x 768 bank, kernel time under rocprofv3 --pmc, tools/microbench/pmc_project.sh): 32 queries
+// 650 us against 779 us (MFMA busy 61 % against 50 % of the SIMD cycles at 2.23 GHz; 399 us is the issue time of the pass's
+// 192 fp32 MFMAs per tile and SIMD); whole call 0.67-0.71 against 0.84-0.88 ms; 16 queries 0.53-0.57 against 0.55-0.59 ms.
+// The time per tile does not depend on where the bank lives (4.5 us per tile and CU from 100 MB = cache-resident to 1.8 GB,
+// tools/microbench/project_latency_probe.py): the pass is bound by its own serial chain, not by HBM.
+// Tried on top and dropped: the two query groups of a workgroup half an iteration apart (group 0 soft-max + GEMM2 while
+// group 1 runs GEMM1 and vice versa, three tile buffers, bit-identical): 726 us, MFMA busy 55 % -- the SIMD issues the older
+// wave's MFMAs first, so the groups do not interleave the way the schedule wants.
+template <int D, int NQG>
+__global__ __launch_bounds__(256 * NQG, 1) void k_project2(const float* __restrict__ bank, const float* __restrict__ inv_norm,
+                                                           int64_t M, const float* __restrict__ q, int N, int q0,
+                                                           float temperature, float* part_acc, float* part_ml, int parts,
+                                                           int slab_unit) {
+  constexpr int STRIDE = D + 4;                  // floats; +16 B skews rows across the 64 banks
+  constexpr int DW = D / 4;                      // channels per wave
+  constexpr int NW = 4 * NQG;                    // waves
+  constexpr int NQ = PR_Q * NQG;                 // queries per pass
+  constexpr int OPR = (D * 4 + 1023) / 1024;     // LDS-DMA operations per bank row (1 KiB each; the last one may be partial)
+  constexpr int OPS = PR_ROWS * OPR;             // ... per tile
+  static_assert(D % 64 == 0 && OPS % NW == 0, "D");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NBUF = 2;                         // tile buffers
+  float* s_tile = lds;                            // [NBUF][16][STRIDE]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wid = wv & 3, grp = wv >> 2;          // channel slice of the wave, query group of the wave
+  float* s_red = lds + NBUF * PR_ROWS * STRIDE + grp * 4 * 256;   // [NQG][4][256]
+  const int li = lane & 15, kq = lane >> 4;
+
+  // slab of rows for this workgroup: the same boundaries as k_project<D, NQG, RT> with slab_unit = 16 RT rows
+  const int64_t units_total = (M + slab_unit - 1) / slab_unit;
+  const int64_t units_per = (units_total + parts - 1) / parts;
+  const int tpu = slab_unit / PR_ROWS;
+  const int64_t t_begin = (int64_t)blockIdx.x * units_per * tpu;
+  int64_t u_end = ((int64_t)blockIdx.x + 1) * units_per;
+  if (u_end > units_total) u_end = units_total;
+  const int64_t t_end = u_end * tpu;              // tiles past M hold copies of row M-1, masked in the soft-max (as in k_project)
+
+  float4 qreg[DW / 16];
+#pragma unroll
+  for (int c = 0; c < DW / 16; ++c) {
+    qreg[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q0 + 16 * grp + li < N)
+      qreg[c] = *(const float4*)(q + (size_t)(q0 + 16 * grp + li) * D + wid * DW + 16 * c + 4 * kq);
+  }
+
+  // tile t -> buffer b: operation o covers 1 KiB of bank row o / OPR; wave wv issues o = wv, wv + NW, ...
+  // Issued through inline asm: a builtin LDS-DMA makes hipcc put s_waitcnt vmcnt(0) in front of the next ds_read of ANY part
+  // of this LDS array (it cannot tell the two tile buffers apart) -- the load of tile t+2 would be waited for right after its
+  // issue.  Hidden like this, hipcc's own vmcnt arithmetic for ordinary loads can only over-wait, never under-wait.
+  const uint32_t lds_tile0 = (uint32_t)(uintptr_t)(pr_lds_ptr_t)s_tile;
+#define PIO_DMA_ASM_S(voff, sbase, ldsaddr)      /* address = 64-bit scalar base + per-lane 32-bit offset */     \
+  do {                                                                                                         \
+    uint32_t _keep;                                                                                            \
+    if (PIO_PROJECT_NT)                                                                                        \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0" \
+                   : "=&s"(_keep) : "v"(voff), "s"(sbase), "s"(ldsaddr) : "memory");                           \
+    else                                                                                                       \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                   : "=&s"(_keep) : "v"(voff), "s"(sbase), "s"(ldsaddr) : "memory");                           \
+  } while (0)
+#define PIO_DMA_ASM_V(vaddr, ldsaddr)            /* address = per-lane 64-bit pointer */                         \
+  do {                                                                                                         \
+    uint32_t _keep;                                                                                            \
+    if (PIO_PROJECT_NT)                                                                                        \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" \
+                   : "=&s"(_keep) : "v"(vaddr), "s"(ldsaddr) : "memory");                                      \
+    else                                                                                                       \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                   : "=&s"(_keep) : "v"(vaddr), "s"(ldsaddr) : "memory");                                      \
+  } while (0)
+  // per-lane byte offsets of this wave's operations inside a tile (constant), for the scalar-base form of the load
+  uint32_t dma_off[OPS / NW];
+#pragma unroll
+  for (int i = 0; i < OPS / NW; ++i) {
+    const int o = wv + NW * i, row = o / OPR, part = o % OPR;
+    dma_off[i] = (uint32_t)((row * D + part * 256 + lane * 4) * 4);
+  }
+#define PIO_DMA_TILE(t, b)                                                                                     \
+  do {                                                                                                         \
+    if (((t) + 1) * PR_ROWS <= M) {            /* every row exists: scalar tile base + the constant lane offsets */ \
+      const float* _base = bank + (t) * PR_ROWS * D;                                                           \
+      _Pragma("unroll") for (int _i = 0; _i < OPS / NW; ++_i) {                                                \
+        const int _o = wv + NW * _i, _row = _o / OPR, _part = _o % OPR;                                        \
+        const uint32_t _dst = __builtin_amdgcn_readfirstlane(lds_tile0 + (uint32_t)((((b) * PR_ROWS + _row) * STRIDE + _part * 256) * 4)); \
+        if (_part * 64 + lane < D / 4) PIO_DMA_ASM_S(dma_off[_i], _base, _dst);                               \
+      }                                                                                                        \
+    } else {                                   /* the bank's last tile: rows past M read row M-1 (masked later) */ \
+      _Pragma("unroll") for (int _i = 0; _i < OPS / NW; ++_i) {                                                \
+        const int _o = wv + NW * _i, _row = _o / OPR, _part = _o % OPR;                                        \
+        int64_t _g = (t) * PR_ROWS + _row;                                                                     \
+        _g = _g < M ? _g : M - 1;                                                                              \
+        const float* _src = bank + _g * D + _part * 256 + lane * 4;                                            \
+        const uint32_t _dst = __builtin_amdgcn_readfirstlane(lds_tile0 + (uint32_t)((((b) * PR_ROWS + _row) * STRIDE + _part * 256) * 4)); \
+        if (_part * 64 + lane < D / 4) PIO_DMA_ASM_V(_src, _dst);                                              \
+      }                                                                                                        \
+    }                                                                                                          \
+  } while (0)
+
+  f32x4 acc[DW / 16];
+#pragma unroll
+  for (int j = 0; j < DW / 16; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;          // for query n = li (replicated over kq and over waves)
+  float p[4] = {0.f, 0.f, 0.f, 0.f}, alpha = 1.0f, rs_part = 0.f;
+  float inv4[4];
+
+  // partial S of the tile in buffer b over this wave's channels -> s_red
+#define PIO_GEMM1(b)                                                                                           \
+  do {                                                                                                         \
+    const float* sb = s_tile + (b) * PR_ROWS * STRIDE;                                                         \
+    f32x4 sp = (f32x4){0.f, 0.f, 0.f, 0.f};                                                                    \
+    _Pragma("unroll") for (int c = 0; c < DW / 16; ++c) {                                                      \
+      const int d = wid * DW + 16 * c + 4 * kq;                                                                \
+      const float4 a = *(const float4*)(sb + li * STRIDE + d);                                                 \
+      const float4 bq = qreg[c];                                                                               \
+      sp = mfma16(a.x, bq.x, sp);                                                                              \
+      sp = mfma16(a.y, bq.y, sp);                                                                              \
+      sp = mfma16(a.z, bq.z, sp);                                                                              \
+      sp = mfma16(a.w, bq.w, sp);                                                                              \
+    }                                                                                                          \
+    *(f32x4*)(s_red + wid * 256 + lane * 4) = sp;                                                              \
+  } while (0)
+  // sum of the four partials, online soft-max for query n = li (this lane's rows are 4 kq + i): p[], alpha, m_run; the
+  // row sum stays partial (rs_part) until PIO_ROWSUM
+#define PIO_SOFTMAX(t)                                                                                         \
+  do {                                                                                                         \
+    f32x4 sfull = *(const f32x4*)(s_red + lane * 4);                                                           \
+    _Pragma("unroll") for (int w = 1; w < 4; ++w) {                                                            \
+      const f32x4 o = *(const f32x4*)(s_red + w * 256 + lane * 4);                                             \
+      sfull += o;                                                                                              \
+    }                                                                                                          \
+    float tmax = -INFINITY;                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+      const int64_t row = (t) * PR_ROWS + 4 * kq + i;                                                          \
+      float z = -INFINITY;                                                                                     \
+      if (row < M) z = (sfull[i] * inv4[i]) / temperature;                                                     \
+      p[i] = z;                                                                                                \
+      tmax = fmaxf(tmax, z);                                                                                   \
+    }                                                                                                          \
+    tmax = xor16_max(tmax);                                                                                    \
+    tmax = xor32_max(tmax);                                                                                    \
+    const float m_new = fmaxf(m_run, tmax);                                                                    \
+    alpha = expf(m_run - m_new);                                                                               \
+    float rs = 0.f;                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+      p[i] = expf(p[i] - m_new);                                                                               \
+      rs += p[i];                                                                                              \
+    }                                                                                                          \
+    rs_part = rs;                                                                                              \
+    m_run = m_new;                                                                                             \
+  } while (0)
+  // Acc[n][d] = Acc * alpha + P^T . bank over the tile in buffer b (this lane's accumulator register i belongs to query 4 kq + i)
+#define PIO_GEMM2(b)                                                                                           \
+  do {                                                                                                         \
+    const float* sb = s_tile + (b) * PR_ROWS * STRIDE;                                                         \
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {                                                     \
+      float al[4];                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) al[i] = __shfl(alpha, 4 * kq + i);                         \
+      _Pragma("unroll") for (int j = 0; j < DW / 16; ++j)                                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[j][i] *= al[i];                                      \
+    }                                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < DW / 16; ++j) {                                                      \
+      f32x4 a4 = acc[j];                                                                                       \
+      const float* bp = sb + (4 * kq) * STRIDE + wid * DW + 16 * j + li;                                       \
+      _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) a4 = mfma16(p[tt], bp[tt * STRIDE], a4);               \
+      acc[j] = a4;                                                                                             \
+    }                                                                                                          \
+  } while (0)
+#define PIO_ROWSUM()                                                                                           \
+  do {                                                                                                         \
+    float rs = rs_part;                                                                                        \
+    rs = xor16_add(rs);                                                                                        \
+    rs = xor32_add(rs);                                                                                        \
+    l_run = l_run * alpha + rs;                                                                                \
+  } while (0)
+#define PIO_LOAD_INV(t)                                                                                        \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+      const int64_t row = (t) * PR_ROWS + 4 * kq + i;                                                          \
+      inv4[i] = inv_norm[row < M ? row : M - 1];                                                               \
+    }                                                                                                          \
+  } while (0)
+#define PIO_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)   /* vmcnt(0), expcnt / lgkmcnt untouched: known to hipcc's own counting */
+#define PIO_RAW_BARRIER()                                                                                      \
+  do {                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  } while (0)
+
+  {
+    if (t_begin < t_end) {
+      PIO_DMA_TILE(t_begin, 0);
+      if (t_begin + 1 < t_end) PIO_DMA_TILE(t_begin + 1, 1);
+      PIO_LOAD_INV(t_begin);
+      PIO_WAIT_VM0();
+      PIO_RAW_BARRIER();
+      PIO_GEMM1(0);
+      PIO_RAW_BARRIER();
+      PIO_SOFTMAX(t_begin);
+    }
+    int cur = 0;
+    for (int64_t t = t_begin; t < t_end; ++t) {
+      const bool more = t + 1 < t_end;
+      float inv_next[4];
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t row = (t + 1) * PR_ROWS + 4 * kq + i;
+          inv_next[i] = inv_norm[row < M ? row : M - 1];
+        }
+      }
+      PIO_GEMM2(cur);
+      PIO_ROWSUM();                     // l_run of tile t, in the shadow of the MFMAs just issued
+      PIO_WAIT_VM0();                   // this wave's share of tile t+1 (issued an iteration ago) and inv_next
+      PIO_RAW_BARRIER();                // A: tile t+1 is complete, nobody reads tile t (or s_red) any more
+      if (t + 2 < t_end) PIO_DMA_TILE(t + 2, cur);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) inv4[i] = inv_next[i];
+        PIO_GEMM1(cur ^ 1);
+        PIO_RAW_BARRIER();              // B: the four partials of the query group are in s_red
+        PIO_SOFTMAX(t + 1);
+      }
+      cur ^= 1;
+    }
+  }
+#undef PIO_DMA_TILE
+#undef PIO_DMA_ASM_S
+#undef PIO_DMA_ASM_V
+#undef PIO_GEMM1
+#undef PIO_SOFTMAX
+#undef PIO_GEMM2
+#undef PIO_ROWSUM
+#undef PIO_LOAD_INV
+#undef PIO_WAIT_VM0
+#undef PIO_RAW_BARRIER
+
+  // ---- partial results: part_acc[block][n][D], part_ml[block][n][2] ----
+  float* pa = part_acc + ((size_t)blockIdx.x * NQ + 16 * grp) * D;
+#pragma unroll
+  for (int j = 0; j < DW / 16; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pa[(size_t)(4 * kq + i) * D + wid * DW + 16 * j + li] = acc[j][i];
+  if (wid == 0 && kq == 0) {
+    part_ml[((size_t)blockIdx.x * NQ + 16 * grp + li) * 2 + 0] = m_run;
+    part_ml[((size_t)blockIdx.x * NQ + 16 * grp + li) * 2 + 1] = l_run;
+  }
+}
+
 // Merge the per-workgroup partials: out[n][d] = sum_b e^{m_b - M} acc_b[n][d] / sum_b e^{m_b - M} l_b.
 // One workgroup per (query, 64 channels): lane = channel, the 4 waves split the partials.
 __global__ __launch_bounds__(256) void k_project_combine(const float* __restrict__ part_acc,
@@ -367,6 +652,19 @@ static hipError_t project_pass(const ProjectArgs& a, int q0, int parts, hipStrea
     hipError_t e = hipFuncSetAttribute((const void*)k_project<D, NQG, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_set = true;
+  }
+  const char* v1 = getenv("PIO_PROJECT_V1");            // read per call: the A/B test flips it inside one process
+  if (!(v1 && v1[0] == '1')) {
+    const int smem2 = (2 * PR_ROWS * (D + 4) + NQG * 4 * 256) * (int)sizeof(float);
+    static bool attr2_set = false;
+    if (!attr2_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)k_project2<D, NQG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+      if (e != hipSuccess) return e;
+      attr2_set = true;
+    }
+    hipLaunchKernelGGL((k_project2<D, NQG>), dim3(parts), dim3(256 * NQG), smem2, s, a.bank, a.inv_norm, a.M, a.q, a.N, q0,
+                       a.temperature, a.part_acc, a.part_ml, parts, PR_ROWS * RT);
+    return hipGetLastError();
   }
   hipLaunchKernelGGL((k_project<D, NQG, RT>), dim3(parts), dim3(256 * NQG), smem, s, a.bank, a.inv_norm, a.M, a.q, a.N, q0,
                      a.temperature, a.part_acc, a.part_ml, parts);

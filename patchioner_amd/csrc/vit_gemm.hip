@@ -357,9 +357,21 @@ static int gemm256_min_tiles() {
   return v;
 }
 
+// One exception, fc1 (GELU epilogue) when its last round of 256-tiles would be mostly empty: at 64 images 792 tiles are
+// 3.09 rounds of 256 CUs and the 128-tile kernel's finer tail wins, 110 vs 116 us (at 80 images, 996 tiles = 3.89 rounds,
+// the 256 kernel wins 125 vs 134; a single round, 204 tiles at 16 images, too: 30 vs 36).
+static bool gemm256_wanted(GemmEpilogue epi, const GemmArgs& a) {
+  const int tiles = ceil_div(a.M, 256) * (a.N / 256);
+  if (tiles < gemm256_min_tiles()) return false;
+  if (epi == EPI_GELU && tiles > 256) {
+    const int rounds = ceil_div(tiles, 256);
+    if (tiles * 100 < rounds * 256 * 85) return false;
+  }
+  return true;
+}
+
 hipError_t launch_vit_gemm(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
-  if (gemm256_min_tiles() > 0 && a.M > 0 && a.N % 256 == 0 && ceil_div(a.M, 256) * (a.N / 256) >= gemm256_min_tiles() &&
-      vit_gemm256_fits(epi, a))
+  if (gemm256_min_tiles() > 0 && a.M > 0 && a.N % 256 == 0 && gemm256_wanted(epi, a) && vit_gemm256_fits(epi, a))
     return launch_vit_gemm256(t, epi, a, s);
   if (a.M <= 0 || a.N % BN != 0 || a.K % (2 * BK) != 0 || a.lda % 8 != 0) return hipErrorInvalidValue;
   // the staging offsets are 32-bit byte offsets from A and W

@@ -262,6 +262,38 @@ def test_projection_full_bank_properties(O):
         e.close()
 
 
+@pytest.mark.parametrize("D,M", [(768, 100003), (768, 2049), (768, 31), (384, 40000), (512, 20011)])
+def test_projection_round2_kernel_is_bit_identical_to_round1(D, M):
+    """k_project2 (two LDS-DMA tile buffers, GEMM2(t) and GEMM1(t+1) back to back, two barriers per tile) performs the
+    arithmetic of k_project in the same order: same bits, for 16- and 32-query passes, ragged query counts, banks that end
+    inside a tile / a slab / hold fewer rows than there are workgroups, zero rows (dropped at load), every bank width."""
+    import os
+    from patchioner_amd.engine import Engine
+    dims = {768: (768, 12), 384: (384, 6), 512: (768, 12)}[D]
+    e = Engine(embed_dim=dims[0], depth=1, num_heads=dims[1], num_registers=4, crop_dim=224, max_batch=1, max_prefixes=128)
+    try:
+        g = torch.Generator().manual_seed(M)
+        bank = torch.randn(M, D, generator=g)
+        bank[::97] *= 3.0
+        if M > 100:
+            bank[5] = 0
+        e.set_memory_bank(bank)
+        for N in (1, 16, 17, 32, 47, 128):
+            q = torch.randn(N, D, generator=g)
+            os.environ.pop("PIO_PROJECT_V1", None)
+            new, nb = e.project(dev(q), normalize=True, n_best=3)
+            os.environ["PIO_PROJECT_V1"] = "1"
+            try:
+                old, ob = e.project(dev(q), normalize=True, n_best=3)
+            finally:
+                os.environ.pop("PIO_PROJECT_V1", None)
+            assert torch.equal(new, old), (D, M, N, float((new - old).abs().max()))
+            assert torch.equal(nb, ob)
+            assert bool(torch.isfinite(new).all())
+    finally:
+        e.close()
+
+
 def test_pinv_golden(golden, O):
     from patchioner_amd.engine import Engine
     g = golden("pinv")
