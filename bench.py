@@ -125,7 +125,7 @@ def main():
                     help="mode=group: model replicas (own ViT workspace, own stream) that stage 1 alternates over")
     ap.add_argument("--decode-streams", type=int, default=int(os.environ.get("PIO_BENCH_DECODE_STREAMS", "3")),
                     help="mode=group: decoders (the model's own + clones on the same weights, each with its own workspace and stream) that consecutive groups' decodes alternate over")
-    ap.add_argument("--vit-batches", type=int, default=int(os.environ.get("PIO_BENCH_VIT_BATCHES", "4")),
+    ap.add_argument("--vit-batches", type=int, default=int(os.environ.get("PIO_BENCH_VIT_BATCHES", "5")),
                     help="mode=group: consecutive bs-16 batches that share one ViT launch (1 = a launch per batch)")
     args = ap.parse_args()
 
@@ -253,7 +253,8 @@ def main():
     prof_pipe = None
     if pipe is not None:
         model.engine.profile_enable(True)
-        run_steps(2 * P)
+        import math
+        run_steps(math.lcm(P, VB) * max(1, (2 * P) // math.lcm(P, VB)))     # whole groups AND whole ViT launches (16 or 40 batches)
         torch.cuda.synchronize()
         prof_pipe = model.engine.profile_read()
         model.engine.profile_enable(False)

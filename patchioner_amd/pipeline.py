@@ -135,8 +135,9 @@ class TraceCaptionPipeline:
         self.groups = self.groups[:1 + len(self.decode_engines)]
 
     # ---- stage 1: everything up to the decoder prefix, on stream A ------------------------------------
-    def _stage(self, g: _Group, held: List) -> None:
-        """One ViT launch for the held batches, then per batch: read-out, region mean, projection."""
+    def _stage(self, held: List) -> None:
+        """One ViT launch for the held batches -- entries (imgs, traces, group): a launch may span the end of one decode group
+        and the start of the next -- then per batch: read-out, region mean, projection into its group's prefix buffer."""
         k = self._nstaged % len(self.stage_models)
         self._nstaged += 1
         m, stream = self.stage_models[k], self.stage_streams[k]
@@ -147,7 +148,7 @@ class TraceCaptionPipeline:
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.eng.device))
         stream.wait_event(ready)
-        for im, _ in held:
+        for im, _, _ in held:
             if im.is_cuda:
                 im.record_stream(stream)
         with torch.cuda.stream(stream):
@@ -155,7 +156,7 @@ class TraceCaptionPipeline:
             want_qkv = self.use_attention_tracing and any(h[1] is not None for h in held)
             tokens_all, qkv_all = eng.vit_forward(imgs, want_qkv=want_qkv)
             s = 0
-            for im, traces in held:
+            for im, traces, g in held:
                 n = im.shape[0]
                 tokens = tokens_all[s:s + n]
                 if traces is None:
@@ -226,36 +227,56 @@ class TraceCaptionPipeline:
         return out
 
     def run(self, batches: Iterable[Tuple[torch.Tensor, Optional[Sequence]]]) -> Iterator[List[str]]:
+        """Batches are dealt to decode groups of ``group_batches`` (or as many as fit ``max_prefixes``) in order; independently
+        of that, every ``vit_batches`` consecutive batches share one ViT launch (a launch may feed the tail of one group and
+        the head of the next: 5 batches of 16 are 83 row tiles x 3 = 249 workgroups on 256 CUs for the N = 768 GEMMs, where 4
+        batches leave 58 CUs idle).  A group is decoded as soon as the launch holding its last batch has been staged."""
         cur = 0
         pending = deque()          # groups whose decode is in flight, oldest first
+        closing: List[_Group] = []  # complete groups whose last batches are still held for their ViT launch
+        n_assigned, rows_assigned = 0, 0
+
+        def launch_held():
+            if self._held:
+                self._stage(self._held)
+                self._held = []
+            for gg in closing:
+                self._decode(gg)
+                pending.append(gg)
+            del closing[:]
+
+        aligned = self.vit_batches <= self.group_batches and self.group_batches % self.vit_batches == 0
         for imgs, traces in batches:
             g = self.groups[cur]
-            if g.busy:             # its previous decode must be collected before the buffer is reused
-                while pending:
-                    for caps in self._collect(pending.popleft()):
-                        yield caps
-            held_rows = sum(h[0].shape[0] for h in self._held)
-            if g.rows + held_rows + imgs.shape[0] > g.prefix.shape[0]:
-                raise ValueError("batch of %d does not fit the %d-prefix decode group" % (imgs.shape[0], g.prefix.shape[0]))
-            self._held.append((imgs, traces))
-            held_rows += imgs.shape[0]
-            full = (len(g.counts) + len(self._held) == self.group_batches or
-                    g.rows + held_rows + imgs.shape[0] > g.prefix.shape[0])
-            if len(self._held) == self.vit_batches or full:
-                self._stage(g, self._held)
-                self._held = []
-            if full:
-                self._decode(g)
-                pending.append(g)
+            n = imgs.shape[0]
+            if n > g.prefix.shape[0]:
+                raise ValueError("batch of %d does not fit the %d-prefix decode group" % (n, g.prefix.shape[0]))
+            if n_assigned and rows_assigned + n > g.prefix.shape[0]:    # a larger batch than the last one: close the group first
+                closing.append(g)
                 cur = (cur + 1) % len(self.groups)
-                if self.groups[cur].busy:          # its buffer is needed now: at most len(groups) - 1 decodes in flight
+                n_assigned, rows_assigned = 0, 0
+                g = self.groups[cur]
+                if aligned:
+                    launch_held()
+            if n_assigned == 0:
+                if any(g is c for c in closing):   # a launch longer than all the group buffers together: send what is held
+                    launch_held()
+                while g.busy:      # its previous decode must be collected before the buffer is reused
                     for caps in self._collect(pending.popleft()):
                         yield caps
+            self._held.append((imgs, traces, g))
+            n_assigned += 1
+            rows_assigned += n
+            if n_assigned == self.group_batches or rows_assigned + n > g.prefix.shape[0]:
+                closing.append(g)
+                cur = (cur + 1) % len(self.groups)
+                n_assigned, rows_assigned = 0, 0
+            # (aligned settings keep the old behaviour: a group's last launch goes out with its last batch)
+            if len(self._held) == self.vit_batches or (closing and aligned):
+                launch_held()
+        launch_held()
         g = self.groups[cur]
-        if self._held:
-            self._stage(g, self._held)
-            self._held = []
-        if g.rows:
+        if n_assigned and g.rows:
             self._decode(g)
             pending.append(g)
         while pending:

@@ -168,6 +168,12 @@ def test_grouped_decode_pipeline_matches_synchronous_forward():
     from patchioner_amd._lib import load
     assert load().pio_destroy(m.engine.h) < 0 and b"clones" in load().pio_last_error()    # the owner outlives its clones
     pipe.close()
+    # a ViT launch longer than a decode group (5 batches per launch, 3 per decode: one launch feeds up to three groups, the
+    # bench's 5-per-launch / 8-per-decode in small) and the other misaligned way round
+    for gb, vb in ((3, 5), (5, 2), (2, 7)):
+        pipe = TraceCaptionPipeline(m, group_batches=gb, vit_batches=vb, decode_clones=1)
+        assert list(pipe.run((imgs, None) for imgs, _ in batches)) == want, (gb, vb)
+        pipe.close()
     # CU-masked streams (pio_stream_create): same captions; close() releases them and the pipeline stays usable
     pipe = TraceCaptionPipeline(m, group_batches=4, stage_cus=192, decode_cus=64)
     assert list(pipe.run((imgs, None) for imgs, _ in batches)) == want

@@ -1,0 +1,66 @@
+"""Host logic of pipeline.TraceCaptionPipeline.run on CPU: which batch goes to which decode group, which batches share a ViT
+launch, when a group is decoded / collected -- with stand-ins for the three GPU stages.  Every batch must come back exactly
+once and in order for any (batches per decode, batches per ViT launch, group buffers, ragged batch sizes), no group may be
+staged into while its decode is in flight, and no group may overflow its prefix buffer."""
+import itertools
+import random
+
+import torch
+
+from patchioner_amd import pipeline as P
+
+
+class _G:
+    def __init__(self, cap):
+        self.prefix = torch.empty(cap, 1)
+        self.rows, self.counts, self.busy, self.items = 0, [], False, []
+
+
+def _make(gb, vb, ngroups, cap=64):
+    p = P.TraceCaptionPipeline.__new__(P.TraceCaptionPipeline)
+    p.groups = [_G(cap) for _ in range(ngroups)]
+    p.group_batches, p.vit_batches, p._held = gb, vb, []
+    launches = []
+
+    def stage(held):
+        launches.append(len(held))
+        for im, tag, g in held:
+            assert not g.busy, "staged into a group whose decode is in flight"
+            g.rows += im.shape[0]
+            g.counts.append(im.shape[0])
+            g.items.append(tag)
+            assert g.rows <= cap and len(g.counts) <= gb
+
+    def decode(g):
+        assert not g.busy and g.rows > 0
+        g.busy, g.out = True, list(g.items)
+
+    def collect(g):
+        assert g.busy
+        out = [[x] for x in g.out]
+        g.rows, g.counts, g.items, g.busy = 0, [], [], False
+        return out
+
+    p._stage, p._decode, p._collect = stage, decode, collect
+    return p, launches
+
+
+def test_every_batch_once_and_in_order_for_any_grouping():
+    rnd = random.Random(1)
+    for gb, vb, ng in itertools.product((1, 2, 3, 4, 5, 8), (1, 2, 3, 4, 5, 7, 8), (2, 3, 4)):
+        for _ in range(6):
+            sizes = [rnd.choice((1, 3, 8, 16, 16, 16)) for _ in range(rnd.randint(0, 23))]
+            p, _ = _make(gb, vb, ng)
+            got = [c[0] for c in p.run((torch.empty(n, 1), i) for i, n in enumerate(sizes))]
+            assert got == list(range(len(sizes))), (gb, vb, ng, sizes, got)
+
+
+def test_bench_setting_fills_every_vit_launch():
+    """bench.py: 8 batches of 16 per decode (128 prefixes), 5 per ViT launch (80 images: 249 of 256 CUs busy in the N = 768
+    GEMMs), 4 group buffers: every launch but the last holds 5 batches although no decode group is a multiple of 5."""
+    p, launches = _make(8, 5, 4, cap=128)
+    got = [c[0] for c in p.run((torch.empty(16, 1), i) for i in range(128))]
+    assert got == list(range(128)) and launches == [5] * 25 + [3]
+    # aligned settings behave as before: a group's last launch goes out with its last batch
+    p, launches = _make(8, 4, 4, cap=128)
+    assert [c[0] for c in p.run((torch.empty(16, 1), i) for i in range(20))] == list(range(20)) and launches == [4] * 5
