@@ -133,6 +133,8 @@ def main():
     rank, world, local = pdist.init_from_env("nccl" if args.gpus > 1 else None)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if os.environ.get("PIO_DIST_SHARE_DEVICE") == "1":      # rehearsal of the N > 1 code path on a one-GPU box (with PIO_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     torch.set_grad_enabled(False)
     import torch.distributed as dist
@@ -289,7 +291,7 @@ def main():
         except ImportError:
             pass
     if world > 1:
-        t = torch.tensor([dt, dt_sync], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, dt_sync], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dt_sync = float(t[0].item()), float(t[1].item())
     sync_stats = _stats(sync_ms)

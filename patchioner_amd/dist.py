@@ -24,6 +24,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        backend = os.environ.get("PIO_DIST_BACKEND") or backend     # rehearsals: gloo with several ranks sharing one GPU
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -44,13 +45,25 @@ def shard_list(items: Sequence, world: int, rank: int):
     return items[s:e]
 
 
+def _gather_into(out: torch.Tensor, src: torch.Tensor, group=None) -> None:
+    """all_gather_into_tensor; gloo has no all-gather for device tensors, so under gloo they cross through the host (the
+    CPU tests and the one-GPU rehearsal of ``bench.py --gpus N``; RCCL gathers device tensors directly)."""
+    if src.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, src.cpu().contiguous(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, src.contiguous(), group=group)
+
+
 def all_gather_ids(ids: torch.Tensor, group=None) -> torch.Tensor:
     """ids [N_local, steps] int32 on this rank -> [N_total, steps] on every rank, rank-major order.
     Ragged shards are padded to the largest shard for a single all-gather and trimmed afterwards."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return ids
     world = dist.get_world_size(group)
-    n_local = torch.tensor([ids.shape[0]], dtype=torch.int64, device=ids.device)
+    cdev = "cpu" if dist.get_backend(group) == "gloo" else ids.device
+    n_local = torch.tensor([ids.shape[0]], dtype=torch.int64, device=cdev)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local, group=group)
     counts = [int(c.item()) for c in counts]
@@ -58,12 +71,12 @@ def all_gather_ids(ids: torch.Tensor, group=None) -> torch.Tensor:
     steps = ids.shape[1]
     if all(c == n_max for c in counts):
         out = torch.empty(world * n_max, steps, dtype=ids.dtype, device=ids.device)
-        dist.all_gather_into_tensor(out, ids.contiguous(), group=group)
+        _gather_into(out, ids, group)
         return out
     padded = torch.zeros(n_max, steps, dtype=ids.dtype, device=ids.device)
     padded[: ids.shape[0]] = ids
     out = torch.empty(world * n_max, steps, dtype=ids.dtype, device=ids.device)
-    dist.all_gather_into_tensor(out, padded, group=group)
+    _gather_into(out, padded, group)
     return torch.cat([out[r * n_max: r * n_max + counts[r]] for r in range(world)], dim=0)
 
 
@@ -73,7 +86,7 @@ def all_gather_equal_ids(ids: torch.Tensor, group=None) -> torch.Tensor:
         return ids
     world = dist.get_world_size(group)
     out = torch.empty(world * ids.shape[0], ids.shape[1], dtype=ids.dtype, device=ids.device)
-    dist.all_gather_into_tensor(out, ids.contiguous(), group=group)
+    _gather_into(out, ids, group)
     return out
 
 
@@ -125,7 +138,7 @@ def gather_group_stream(groups, n_groups_local: int, steps: int = 30, device=Non
         for ids in groups:
             yield ids
         return
-    t = torch.tensor([n_groups_local], dtype=torch.int64, device=device)
+    t = torch.tensor([n_groups_local], dtype=torch.int64, device="cpu" if dist.get_backend(group) == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     rounds = int(t.item())
     it = iter(groups)
