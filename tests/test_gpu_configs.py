@@ -87,6 +87,13 @@ def test_config4_capdec_dense_boxes_chunked(O):
     ids, _ = m.engine.decode_greedy(feats)
     ref_ids, _, margin = O.DeCapOracle(W.synth_decap(3)).decode_ids(feats.cpu())
     assert np.array_equal(ids.cpu().numpy(), ref_ids.numpy()), "min margin %.2e" % float(margin.min())
+    # config 4's multi-GPU driver on the real model (no process group = one shard; the 2-rank sharding itself is tested with
+    # gloo in tests/test_dist_cpu.py): nested [B][NB] captions of the forward, the caller's boxes floor-divided in place
+    from patchioner_amd import dist as pdist
+    mine = boxes.clone()
+    nested = pdist.sharded_box_captions(m, imgs.cuda(), mine, lambda rows: m.tokenizer.batch_captions(rows), gaussian_avg=True,
+                                        gaussian_bbox_variance=0.5)
+    assert nested == got["bbox_capts"] and torch.equal(mine, boxes // 14)
 
 
 def test_config5_backbone_vitl14(O):

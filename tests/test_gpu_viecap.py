@@ -159,3 +159,62 @@ def test_config5_shape_vitl14_fp16_attention_weighted_traces(O):
     _explained(orc.last["margins"], ids, orc.last["ids"], "config 5 shape (ViT-L/14, 16 traces)")
     if torch.equal(ids, orc.last["ids"]):
         assert out["trace_capts"] == want
+
+
+def test_config5_full_size_vitl14_depth24_batch128(O):
+    """BASELINE config 5 at its full per-GPU size: ViT-L/14-reg at its full depth 24 (1024 wide, 16 heads), fp16 operands,
+    batch 128, attention-weighted trace regions, ViECap head (hard + soft prompt, 64 greedy steps).  The CPU oracle cannot
+    follow 128 images in a test's time, so: (i) the backbone's tokens of 2 of the 128 images against the fp32 oracle at the
+    full depth; (ii) composition: the first 16 images captioned on their own give the captions they get inside the batch of
+    128 (every stage is per-image, whatever the launch holds); (iii) the head stage-wise on 16 of the 128 rows: hard-prompt
+    token ids exact and greedy ids exact against the oracle on the HIP path's own region features (near-ties explained)."""
+    vocab, merges = W.synth_bpe(0)
+    tok = V.ByteLevelBPE(vocab, merges)
+    w = W.synth_viecap(311, clip_hidden_size=1024, n_layer=12, tok_vocab=len(vocab))
+    ents = list(W.SYNTH_ENTITIES)
+    emb = W.synth_entity_embeddings(312, len(ents), 1024)
+    sd = W.synth_dinov2(93, "dinov2_vitl14_reg")
+    m = _model(_viecap_cfg(w, tok, ents, emb, 1024), dino="dinov2_vitl14_reg", depth=None, vit_dtype="fp16", max_batch=64,
+               max_prefixes=128, dino_weights=sd)
+    B = 128
+    imgs = W.synth_images(8, B, 224).cuda()
+    traces = [gc.block_trace(i % 13, (5 * i) % 13) for i in range(B)]
+    eng = m.engine
+    # (i) full-depth backbone vs the oracle
+    pick = [0, 77]
+    tokens, qkv = eng.vit_forward(imgs)
+    vit = O.DinoV2Oracle(sd, num_heads=16)
+    d = vit(imgs[pick].cpu())
+    ref = torch.cat([d["x_norm_clstoken"][:, None], d["x_norm_regtokens"], d["x_norm_patchtokens"]], 1)
+    err = float((tokens[pick].cpu() - ref).abs().max() / ref.abs().max())
+    print("ViT-L/14 depth 24, images %s of 128: rel-max-err %.2e" % (pick, err))
+    assert err <= 4e-3 and bool(torch.isfinite(tokens).all())
+    # (ii) the whole forward at batch 128; composition of everything per-image (backbone, read-out, region means): the first
+    # 16 images on their own give bitwise the region features they have inside the batch.  (Captions are NOT composable in
+    # the reference either: hard prompts are padded to the batch's longest with pad id 0 and no mask, entrypoint.py:126.)
+    out = m(imgs, get_cls_capt=False, traces=traces, use_attention_tracing=True)
+    caps = out["trace_capts"]
+    ids_all = m.viecap.last_ids.cpu().long().clone()
+    prompts_all = m.viecap.last_prompt_tokens.clone()
+    assert len(caps) == B and all(isinstance(s, str) for s in caps) and ids_all.shape == (B, 64)
+    self_attn, _, _, _ = eng.cls_attention(qkv, tokens)
+    feats = eng.region_reduce(tokens, self_attn * eng.trace_grids(traces).view(B, -1), None, 1.0 / m.num_patch_tokens)
+    t16, q16 = eng.vit_forward(imgs[:16].clone())
+    sa16, _, _, _ = eng.cls_attention(q16, t16)
+    f16 = eng.region_reduce(t16, sa16 * eng.trace_grids(traces[:16]).view(16, -1), None, 1.0 / m.num_patch_tokens)
+    assert torch.equal(t16, tokens[:16]) and torch.equal(f16, feats[:16])
+    # (iii) the head on 16 rows spread over the batch, on the HIP path's own region features
+    rows = list(range(0, B, 8))
+    sub = feats[rows].clone()
+    got = m.viecap.forward(sub.clone())
+    ids = m.viecap.last_ids.cpu().long()
+    orc = O.ViECapOracle(w, tok, ents, emb, temperature=0.01, top_k=3, threshold=0.4, using_hard_prompt=True, soft_prompt_first=True)
+    want = orc.forward(sub.cpu().clone())
+    assert np.array_equal(m.viecap.last_prompt_tokens.numpy(), orc.last["prompt_tokens"].numpy())
+    _explained(orc.last["margins"], ids, orc.last["ids"], "config 5 full size (ViT-L/14 x 24, 16 of 128 rows)")
+    if torch.equal(ids, orc.last["ids"]):
+        assert got == want
+    # ... and each of those rows carried the same hard prompt (before padding) inside the batch of 128
+    for k, r in enumerate(rows):
+        a_, b_ = prompts_all[r].tolist(), m.viecap.last_prompt_tokens[k].tolist()
+        assert [t for t in a_ if t != 0] == [t for t in b_ if t != 0]      # the two runs pad to different lengths (pad id 0)
