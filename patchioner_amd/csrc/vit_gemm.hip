@@ -8,15 +8,19 @@
 // embedding add, q/k/v head split (+ the fp32 capture the qkv forward hook takes,
 // P/src/dino_extraction.py:7-9), LayerScale + residual add, exact-erf GELU.
 //
-// Tiling: BM x 128 x 64 per 256-thread workgroup, BM = 128 (4 waves as 2x2, each wave 64x64 = 2x2 MFMA
-// tiles) for the wide GEMMs, BM = 64 (each wave 32x64) for the N = D ones so that they still give >= 1.5
-// workgroups per CU at 16 images.  Operand tiles are register-staged into double-buffered LDS with a
-// two-K-tile prefetch distance (two named register sets), one barrier per K-tile.  LDS rows are 128 B
-// (64 halfs); the 16-B chunk index is XORed with (row>>1)&7 so that the ds_read_b128 fragment reads of a
-// 16-lane group fall on 16 distinct 16-B slots of the 256-B bank row (conflict-free), while the staging
-// ds_write_b128 of 8 consecutive lanes covers one whole row half.  The epilogue passes the accumulators
-// through LDS so that every global access is a row-major 16 B (fp32) / 8 B (half) per lane.
-// Workgroup ids are remapped so that each XCD's L2 sees a contiguous run of tiles sharing A panels.
+// This file: the dispatch (launch_vit_gemm) and k_vit_gemm, the 128-wide kernel that serves GEMMs with fewer than ~150
+// tiles of 256 x 256 (a synchronous 16-image forward's proj / fc2, small box-sequence batches); larger ones go to
+// k_vit_gemm256 (vit_gemm256.hip), which computes every output element with the same k order -- identical bits.
+//
+// k_vit_gemm tiling: BM x 128 x 64 per 256-thread workgroup, BM = 128 (4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles)
+// for the wide GEMMs, BM = 64 (each wave 32x64) for the N = D ones so that they still give >= 1.5 workgroups per CU at 16
+// images.  Operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write): the
+// wide GEMMs use ONE 32-KiB buffer with up to four workgroups per CU covering each other's load latency, the N = D GEMMs
+// two buffers (one barrier per K-tile).  LDS rows are 128 B (64 halfs); an LDS-DMA writes lane-linearly, so the XOR
+// swizzle that makes the ds_read_b128 fragment reads of a 16-lane group fall on 16 distinct 16-B slots (conflict-free) is
+// applied to each lane's SOURCE address instead.  The epilogue passes the accumulators through LDS so that every global
+// access is a row-major 16 B (fp32) / 8 B (half) per lane; V is stored transposed straight from the registers
+// (v_permlane32_swap).  Workgroup ids are remapped so that each XCD's L2 sees a contiguous run of tiles sharing A panels.
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
