@@ -196,7 +196,7 @@ int pio_decode_greedy(pio_handle h, const float* prefix_dev, int32_t N, int32_t 
 /* ---- ViECap head (P/src/model.py:1394-1398 -> P/src/viecap/entrypoint.py:98-153) -----------------------
  * Weights arrive through pio_load_weight under the checkpoint's own names: `mapping_network.*` (ClipCap.py:122-153) and
  * `gpt.transformer.*` (GPT2LMHeadModel; stored like DeCap's `decoder.transformer.*`).  pio_create: dec_layers = 12,
- * dec_heads = 12, max_steps >= continuous prompt + hard prompt + 63. */
+ * dec_heads = 12, max_steps >= continuous prompt + hard prompt + 63 (and >= the longest caption pio_lm_score is to score; <= 256). */
 /* Entity vocabulary embeddings [K, C] (host; retrieval_categories.py:61-95 normalises them per call: done once here). */
 int pio_viecap_set_entities(pio_handle h, const float* host_embeddings, int32_t K, int32_t C);
 /* continuous_prompt_length of the loaded mapping network (rows of prefix_const), 0 without one */
@@ -207,6 +207,13 @@ int pio_viecap_mapping(pio_handle h, float* feats, int32_t N, float* out, pio_st
 /* image_text_simiarlity (retrieval_categories.py:61-95) on the already normalised feats: out [N, K] =
  * softmax(feats . entities^T / temperature). */
 int pio_viecap_entity_logits(pio_handle h, const float* feats, int32_t N, float temperature, float* out, pio_stream stream);
+/* VieCap.compute_perplexity (P/src/viecap/entrypoint.py:155-172): GPT2LMHeadModel(input_ids, labels = input_ids).loss per
+ * caption, as a sum.  tokens [N, Lmax] int32 (row n holds lens[n] token ids, the rest is ignored), lens [N] int32, all on
+ * the device; nll [N] receives sum_{p + 1 < lens[n]} -log p(token_{p+1} | token_0..p) (exact fp32 head), so that the
+ * reference's loss is nll / (lens - 1) and its perplexity exp of that (lens = 1: 0 / 0, NaN, as in the reference).
+ * 1 <= N <= min(max_prefixes, 64), Lmax <= max_steps. */
+int pio_lm_score(pio_handle h, const int32_t* tokens, const int32_t* lens, int32_t N, int32_t Lmax, float* nll, pio_stream stream);
+
 /* word_embed + torch.cat + greedy_search (entrypoint.py:126-150, search.py:108-191): cont [N, Lc, 768] soft prompt,
  * tokens [N, Lt] int32 hard-prompt ids already padded to one length (pad_sequence), soft_first as in the config; `steps`
  * greedy tokens (64 in the reference) with a KV cache, no attention mask, no early stop -> ids [N, steps] int32. */

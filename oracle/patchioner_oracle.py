@@ -766,3 +766,24 @@ class ViECapOracle:
                     break
             out.append(self.tok.decode(r[:i + 1]))
         return out
+
+    def compute_perplexity(self, sentences) -> List[float]:
+        """``VieCap.compute_perplexity`` (P/src/viecap/entrypoint.py:155-172): each sentence is tokenised again and run
+        through the language model with ``labels = input_ids``: loss = mean cross-entropy of token p+1 given tokens <= p
+        over the L - 1 positions (GPT2LMHeadModel shifts by one), perplexity = exp(loss); one token: mean of nothing, NaN."""
+        out = []
+        for sentence in sentences:
+            ids = torch.tensor(self.tok.encode(sentence), dtype=torch.long)
+            if ids.numel() < 2:
+                out.append(float("nan"))
+                continue
+            logits = self._logits_of_tokens(ids)
+            loss = F.cross_entropy(logits[:-1], ids[1:])
+            out.append(float(torch.exp(loss)))
+        return out
+
+    def _logits_of_tokens(self, ids: torch.Tensor) -> torch.Tensor:
+        """GPT2LMHeadModel(input_ids=ids).logits [L, V]: word + position embeddings, the causal stack, the tied head -- one
+        full forward over the sentence, as the reference runs it."""
+        wte = self.gpt.w["decoder.transformer.wte.weight"]
+        return self.gpt.gpt2_logits(wte[ids].unsqueeze(0))[0]

@@ -65,6 +65,7 @@ SIGNATURES = {
     "pio_viecap_set_entities": (c_int32, [c_void_p, c_void_p, c_int32, c_int32]),
     "pio_viecap_mapping": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "pio_viecap_entity_logits": (c_int32, [c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p]),
+    "pio_lm_score": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "pio_viecap_decode": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "pio_mem_topk": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "pio_text_project": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32,

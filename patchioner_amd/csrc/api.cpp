@@ -585,8 +585,8 @@ int pio_create(const pio_config* cfg, pio_handle* out) {
     return fail(PIO_ERR_INVALID_ARG, "pio_create: backbone head_dim must be 64 (embed_dim = 64 * num_heads)");
   if (cfg->crop_dim % cfg->patch_size != 0)
     return fail(PIO_ERR_INVALID_ARG, "pio_create: crop_dim must be a multiple of patch_size");
-  if (cfg->max_batch < 1 || cfg->max_prefixes < 1 || cfg->max_prefixes > 128 || cfg->max_steps < 1 || cfg->max_steps > 128)
-    return fail(PIO_ERR_INVALID_ARG, "pio_create: capacities out of range (prefixes <= 128, decoder positions <= 128)");
+  if (cfg->max_batch < 1 || cfg->max_prefixes < 1 || cfg->max_prefixes > 128 || cfg->max_steps < 1 || cfg->max_steps > 256)
+    return fail(PIO_ERR_INVALID_ARG, "pio_create: capacities out of range (prefixes <= 128, decoder positions <= 256)");
   if (cfg->readout_heads != 16 && cfg->readout_heads * 64 != cfg->embed_dim)
     return fail(PIO_ERR_INVALID_ARG, "pio_create: readout_heads must be 16, or embed_dim / 64 (ViT-S: 6)");
   int ndev = 0;
@@ -1091,6 +1091,26 @@ int pio_viecap_entity_logits(pio_handle c, const float* feats, int32_t N, float 
   // softmax(f t^T / T) over the vocabulary (retrieval_categories.py:92-93); f is the already normalised feature
   HIP_OK(launch_sgemm_tn(feats, c->map_C, c->ent, c->map_C, nullptr, 1.0f / temperature, out, c->ent_K, N, c->ent_K, c->map_C, 0, 0, s));
   HIP_OK(launch_softmax_rows(out, out, N, c->ent_K, s));
+  return PIO_OK;
+}
+
+int pio_lm_score(pio_handle c, const int32_t* tokens, const int32_t* lens, int32_t N, int32_t Lmax, float* nll, pio_stream stream) {
+  if (!c || !tokens || !lens || !nll) return fail(PIO_ERR_INVALID_ARG, "pio_lm_score: null argument");
+  if (!c->has_dec) return fail(PIO_ERR_NOT_READY, "pio_lm_score: language model not loaded");
+  if (N < 1 || N > c->cfg.max_prefixes || N > 64) return fail(PIO_ERR_CAPACITY, "pio_lm_score: 1 <= N <= min(max_prefixes, 64) rows per call");
+  if (Lmax < 1 || Lmax > c->cfg.max_steps || Lmax > 256) return fail(PIO_ERR_CAPACITY, "pio_lm_score: Lmax above max_steps");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  DecoderArgs a;
+  a.N = N; a.steps = 1; a.E = c->cfg.dec_embd; a.heads = c->cfg.dec_heads; a.layers = c->cfg.dec_layers; a.vocab = c->cfg.dec_vocab;
+  a.prefix_size = c->cfg.prefix_size; a.eps = c->cfg.dec_ln_eps; a.prefix = nullptr; a.clip_w = nullptr; a.clip_b = nullptr;
+  a.wte = c->wte; a.wpe = c->wpe; a.head_w = c->head_w; a.head_c = c->head_c; a.head_d = c->head_d; a.layer = c->dl.data();
+  a.x = c->dx; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.splitk_ws = c->splitk_ws; a.splitk_cnt = c->splitk_cnt;
+  a.kcache = c->kcache; a.vcache = c->vcache; a.max_steps = c->cfg.max_steps; a.logits = c->logits; a.ids = c->ids_buf; a.logprob = nullptr;
+  a.head_w16 = c->head_w16; a.head_w16_unscale = c->head_w16_unscale; a.head_bound_coef = c->head_bound_coef;
+  a.xh = c->dec_xh; a.lm_stats = c->lm_stats; a.lm_gmax = c->lm_gmax; a.pos_base = 0;
+  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, 64 * sizeof(unsigned), s));
+  HIP_OK(launch_lm_score(a, tokens, lens, Lmax, nll, s));
   return PIO_OK;
 }
 

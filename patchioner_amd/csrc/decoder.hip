@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? PIO_DEC_GEMM_WAVES : 1) void k
 //            the NJ partial sums meet in LDS.
 __global__ __launch_bounds__(256) void k_dec_attention(const float* __restrict__ qkv, float* kcache, float* vcache,
                                                        int E, int heads, int pos, int max_steps, float* att) {
-  __shared__ float s_sc[128];
+  __shared__ float s_sc[256];
   __shared__ __attribute__((aligned(16))) float s_o[5][256];
   const int n = blockIdx.x / heads, h = blockIdx.x - n * heads;
   const int tid = threadIdx.x;
@@ -377,15 +377,21 @@ __global__ __launch_bounds__(256) void k_dec_attention(const float* __restrict__
     vc[(size_t)pos * E + tid] = vn[tid];
   }
   __syncthreads();
-  if (tid < 64) {                                   // soft-max over the <= 128 scores once, by one wave (two per lane)
+  if (tid < 64) {                                   // soft-max over the <= 256 scores once, by one wave (four per lane)
     const float sc = tid <= pos ? s_sc[tid] : -INFINITY;
     const float sc2 = tid + 64 <= pos ? s_sc[tid + 64] : -INFINITY;
-    const float mx = wave_max(fmaxf(sc, sc2));
+    const float sc3 = tid + 128 <= pos ? s_sc[tid + 128] : -INFINITY;
+    const float sc4 = tid + 192 <= pos ? s_sc[tid + 192] : -INFINITY;
+    const float mx = wave_max(fmaxf(fmaxf(sc, sc2), fmaxf(sc3, sc4)));
     const float e = tid <= pos ? expf(sc - mx) : 0.f;
-    const float e2 = tid + 64 <= pos ? expf(sc2 - mx) : 0.f;    // pos < 64: 0, and e + 0 is e (the DeCap sums do not change)
-    const float inv = 1.0f / wave_sum(e + e2);
+    const float e2 = tid + 64 <= pos ? expf(sc2 - mx) : 0.f;    // a lane's absent terms are +0: e + 0 is e, so the sums of the
+    const float e3 = tid + 128 <= pos ? expf(sc3 - mx) : 0.f;   // 30-step DeCap decode (pos < 64) and of the 128-position
+    const float e4 = tid + 192 <= pos ? expf(sc4 - mx) : 0.f;   // ViECap search are the bits they were with two per lane
+    const float inv = 1.0f / wave_sum(((e + e2) + e3) + e4);
     s_sc[tid] = e * inv;
     s_sc[tid + 64] = e2 * inv;
+    s_sc[tid + 128] = e3 * inv;
+    s_sc[tid + 192] = e4 * inv;
   }
   __syncthreads();
   if (jg < NJ) {
@@ -1404,7 +1410,7 @@ static hipError_t dec_head_step(const DecoderArgs& a, int step, bool filtered, h
 }
 
 static bool dec_args_ok(const DecoderArgs& a, bool filtered, int positions) {
-  return positions <= a.max_steps && positions <= 128 && a.steps <= 64 && a.E == 768 && (a.E / a.heads) % 32 == 0 &&
+  return positions <= a.max_steps && positions <= 256 && a.steps <= 64 && a.E == 768 && (a.E / a.heads) % 32 == 0 &&
          (a.E / a.heads) <= 256 && a.N <= (filtered ? 128 : 64) && ceil_div(a.vocab, 16) <= 4096;
 }
 
@@ -1434,6 +1440,81 @@ __global__ __launch_bounds__(256) void k_dec_prompt_x(const float* __restrict__ 
 // chosen from the logits of position P-1+k is ids[.][k] and becomes position P+k.  The reference's 64 iterations run
 // the prompt forward plus 64 single-token forwards and never use the logits of the last one: P + steps - 1 positions here.
 // a.pos_base must be P - 1.
+// ---- teacher-forced scoring: GPT2LMHeadModel(input_ids, labels = input_ids).loss as VieCap.compute_perplexity takes it
+// (P/src/viecap/entrypoint.py:155-172): the tokens of a finished caption go through the KV-cached layers position by
+// position; after position p the exact head gives log sum exp over the vocabulary (the partials of k_lmhead_wide) and one
+// more dot product the logit of the NEXT token; nll[n] accumulates their difference for p + 1 < lens[n].
+__global__ __launch_bounds__(256) void k_dec_token_x(const int32_t* __restrict__ tokens, int Lmax, int pos, const float* __restrict__ wte,
+                                                     const float* __restrict__ wpe, int E, int V, float* x) {
+  const int n = blockIdx.x;
+  int t = tokens[(size_t)n * Lmax + pos];
+  t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+  for (int d = threadIdx.x; d < E; d += 256) x[(size_t)n * E + d] = wte[(size_t)t * E + d] + wpe[(size_t)pos * E + d];
+}
+
+__global__ __launch_bounds__(256) void k_dec_score(const float* __restrict__ part, int nblk, int N, int E, int V,
+                                                   const float* __restrict__ x, const float* __restrict__ head_w,
+                                                   const float* __restrict__ head_c, const float* __restrict__ head_d, float eps,
+                                                   const int32_t* __restrict__ tokens, const int32_t* __restrict__ lens, int Lmax, int pos,
+                                                   float* nll) {
+  __shared__ float s_a[4], s_b[4], s_c[4];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (pos + 1 >= lens[n]) return;                    // block-uniform
+  int label = tokens[(size_t)n * Lmax + pos + 1];
+  label = label < 0 ? 0 : (label >= V ? V - 1 : label);
+  // log sum exp of the row's logits from the head's per-block (max, arg-max, sum of exp relative to the max) partials
+  float bv = -INFINITY;
+  for (int b = tid; b < nblk; b += 256) bv = fmaxf(bv, part[((size_t)b * N + n) * 4]);
+  bv = wave_max(bv);
+  if (lane == 0) s_a[wid] = bv;
+  __syncthreads();
+  bv = fmaxf(fmaxf(s_a[0], s_a[1]), fmaxf(s_a[2], s_a[3]));
+  float se = 0.f;
+  for (int b = tid; b < nblk; b += 256) {
+    const float4 pr = *(const float4*)(part + ((size_t)b * N + n) * 4);
+    se += pr.z * expf(pr.x - bv);
+  }
+  // the label's logit as the head computes it: rstd (W'_v . x - mu c_v) + d_v with the row's LayerNorm statistics
+  const float* xr = x + (size_t)n * E;
+  const float* wr = head_w + (size_t)label * E;
+  float sx = 0.f, sq = 0.f, dot = 0.f;
+  for (int d = tid; d < E; d += 256) {
+    const float v = xr[d];
+    sx += v; sq += v * v; dot += wr[d] * v;
+  }
+  se = wave_sum(se); sx = wave_sum(sx); sq = wave_sum(sq); dot = wave_sum(dot);
+  __syncthreads();
+  if (lane == 0) { s_a[wid] = se; s_b[wid] = sx; s_c[wid] = sq; }
+  __syncthreads();
+  se = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
+  sx = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
+  sq = (s_c[0] + s_c[1]) + (s_c[2] + s_c[3]);
+  __syncthreads();
+  if (lane == 0) s_a[wid] = dot;
+  __syncthreads();
+  if (tid == 0) {
+    dot = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
+    const float mu = sx / (float)E;
+    const float var = fmaxf(sq / (float)E - mu * mu, 0.f);
+    const float logit = rsqrtf(var + eps) * (dot - mu * head_c[label]) + head_d[label];
+    nll[n] += (bv + logf(se)) - logit;
+  }
+}
+
+hipError_t launch_lm_score(const DecoderArgs& a, const int32_t* tokens, const int32_t* lens, int Lmax, float* nll, hipStream_t s) {
+  if (a.N < 1 || a.N > 64 || Lmax < 1 || Lmax > a.max_steps || !dec_args_ok(a, false, Lmax)) return hipErrorInvalidValue;
+  PIO_TRY(hipMemsetAsync(nll, 0, (size_t)a.N * sizeof(float), s));
+  for (int pos = 0; pos + 1 < Lmax; ++pos) {
+    hipLaunchKernelGGL(k_dec_token_x, dim3(a.N), dim3(256), 0, s, tokens, Lmax, pos, a.wte, a.wpe, a.E, a.vocab, a.x);
+    PIO_TRY(dec_layers_step(a, pos, s));
+    int nblk = 0;
+    PIO_TRY(launch_lmhead(a.head_w, a.x, a.N, a.vocab, a.E, a.head_d, a.head_c, a.eps, a.logits, &nblk, s));
+    hipLaunchKernelGGL(k_dec_score, dim3(a.N), dim3(256), 0, s, a.logits, nblk, a.N, a.E, a.vocab, a.x, a.head_w, a.head_c, a.head_d,
+                       a.eps, tokens, lens, Lmax, pos, nll);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_decode_prompted(const DecoderArgs& a, const float* prompt, int P, hipStream_t s) {
   const bool filtered = PIO_LMHEAD_FILTER && a.logprob == nullptr && a.head_w16 != nullptr;
   if (P < 1 || a.steps < 1 || a.pos_base != P - 1 || !dec_args_ok(a, filtered, P + a.steps - 1)) return hipErrorInvalidValue;

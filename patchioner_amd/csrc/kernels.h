@@ -150,6 +150,8 @@ struct DecoderArgs {
 hipError_t launch_decode_greedy(const DecoderArgs& a, hipStream_t s);
 // ViECap greedy search: prompt [N][P][E] at positions 0..P-1, then a.steps greedy tokens (a.pos_base = P - 1)
 hipError_t launch_decode_prompted(const DecoderArgs& a, const float* prompt, int P, hipStream_t s);
+// teacher-forced pass over given tokens [N][Lmax] (rows of lens[n] tokens): nll[n] = sum over p + 1 < lens[n] of -log p(token p+1 | tokens <= p); N <= 64
+hipError_t launch_lm_score(const DecoderArgs& a, const int32_t* tokens, const int32_t* lens, int Lmax, float* nll, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // ViECap head (viecap.hip): mapping network, entity logits, prompt assembly -- all fp32

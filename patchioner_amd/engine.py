@@ -379,6 +379,23 @@ class Engine:
         check(self.lib.pio_viecap_entity_logits(self.h, ptr(feats), N, float(temperature), ptr(out), _stream()))
         return out
 
+    def lm_score(self, rows) -> torch.Tensor:
+        """Teacher-forced negative log-likelihood sums of token rows (list of lists of ids) under the language model
+        (pio_lm_score): [N] float32 on the device; the reference's loss is this / (len - 1)."""
+        N = len(rows)
+        out = torch.empty(N, device=self.device, dtype=torch.float32)
+        cap = min(self.max_prefixes, 64)
+        for s in range(0, N, cap):
+            chunk = rows[s:s + cap]
+            L = max(1, max(len(r) for r in chunk))
+            tok = torch.zeros(len(chunk), L, dtype=torch.int32)
+            for i, r in enumerate(chunk):
+                tok[i, :len(r)] = torch.tensor(r, dtype=torch.int32)
+            lens = torch.tensor([len(r) for r in chunk], dtype=torch.int32)
+            tok_d, lens_d = self._dev(tok, torch.int32), self._dev(lens, torch.int32)
+            check(self.lib.pio_lm_score(self.h, ptr(tok_d), ptr(lens_d), len(chunk), L, ptr(out[s:s + cap]), _stream()))
+        return out
+
     def viecap_decode(self, cont: torch.Tensor, tokens: Optional[torch.Tensor], soft_first: bool = True, steps: int = 64) -> torch.Tensor:
         """cont [N, Lc, E] device, tokens [N, Lt] int32 (host or device) or None -> greedy ids [N, steps] int32."""
         N = cont.shape[0]

@@ -182,7 +182,7 @@ class Patchioner(nn.Module):
         dec_kw = {}
         if viecap_sd is not None:
             n_layer = 1 + max(int(k.split(".")[3]) for k in viecap_sd if k.startswith("gpt.transformer.h."))
-            dec_kw = dict(dec_layers=n_layer, dec_heads=12, max_steps=128,
+            dec_kw = dict(dec_layers=n_layer, dec_heads=12, max_steps=256,
                           dec_vocab=int(viecap_sd["gpt.transformer.wte.weight"].shape[0]),
                           dec_positions=int(viecap_sd["gpt.transformer.wpe.weight"].shape[0]))
         self.engine = Engine(embed_dim=self.embed_dim, depth=depth, num_heads=heads,

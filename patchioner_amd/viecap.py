@@ -193,9 +193,6 @@ class VieCapHead:
     def forward(self, image_features: torch.Tensor, compute_scores: bool = False):
         """entrypoint.py:98-153.  image_features [N, clip_hidden_size] is L2-normalised IN PLACE (line 108)."""
         a, eng = self.args, self.engine
-        if compute_scores:
-            raise NotImplementedError("ViECap perplexity scores (entrypoint.py:155-172) re-tokenise the captions and run a "
-                                      "teacher-forced language-model pass: not built")
         pad_id = self.tokenizer.pad_token_id if self.tokenizer.pad_token_id is not None else 0
         x = image_features
         if not isinstance(x, torch.Tensor):
@@ -225,19 +222,33 @@ class VieCapHead:
         if N == 1:
             # search.py:172-181: a single caption stops at its first full stop and comes back as a str, not a list
             r = rows[0]
+            out = self.tokenizer.decode(r)
             for i, t in enumerate(r):
                 if t in self.eos:
-                    return self.tokenizer.decode(r[:i + 1])
-            return self.tokenizer.decode(r)
-        out = []
-        for r in rows:
-            i = len(r) - 1
-            for j, t in enumerate(r):
-                if t in self.eos:
-                    i = j
+                    out = self.tokenizer.decode(r[:i + 1])
                     break
-            out.append(self.tokenizer.decode(r[:i + 1]))
+        else:
+            out = []
+            for r in rows:
+                i = len(r) - 1
+                for j, t in enumerate(r):
+                    if t in self.eos:
+                        i = j
+                        break
+                out.append(self.tokenizer.decode(r[:i + 1]))
+        if compute_scores:
+            return out, self.compute_perplexity(out)
         return out
+
+    def compute_perplexity(self, sentences) -> List[float]:
+        """entrypoint.py:155-172: every caption is tokenised again and scored by the language model with labels = inputs:
+        perplexity = exp(mean over the L - 1 next-token losses).  ``for sentence in sentences`` over a single caption (a str,
+        from the N == 1 branch of the search) walks its CHARACTERS in the reference; kept."""
+        rows = [self.tokenizer.encode(s) for s in sentences]
+        if not rows:
+            return []
+        nll = self.engine.lm_score(rows).cpu()
+        return [float(torch.exp(nll[i] / (len(r) - 1))) if len(r) > 1 else float("nan") for i, r in enumerate(rows)]
 
 
 def load_viecap_weights(cfg: dict) -> Dict[str, torch.Tensor]:

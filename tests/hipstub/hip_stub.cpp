@@ -65,6 +65,7 @@ hipError_t launch_activation_f32(float*, size_t, int, hipStream_t) { return hipS
 hipError_t launch_revert(const float*, const float*, const float*, int, int, int, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_decode_greedy(const DecoderArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_decode_prompted(const DecoderArgs&, const float*, int, hipStream_t) { return hipSuccess; }
+hipError_t launch_lm_score(const DecoderArgs&, const int32_t*, const int32_t*, int, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_viecap_mapping(const ViecapMapArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_sgemm_tn(const float*, int, const float*, int, const float*, float, float*, int, int, int, int, int, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_build_prompt(const float*, const int32_t*, const float*, int, int, int, int, int, int, float*, hipStream_t) { return hipSuccess; }

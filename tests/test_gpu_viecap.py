@@ -112,8 +112,18 @@ def test_viecap_pieces_vs_reference_and_oracle(O, golden, case):
         assert one == meta["single_sentence"] == want1
     with pytest.raises(Exception):
         m.caption_tokens(x.clone().cuda(), return_n_best_sims=2)
-    with pytest.raises(NotImplementedError):
-        m.caption_tokens(x.clone().cuda(), compute_scores=True)
+    # compute_scores: VieCap.compute_perplexity (entrypoint.py:155-172) -- the teacher-forced pass (pio_lm_score, exact fp32
+    # head) on the reference's own sentences against the reference's perplexities, and through caption_tokens
+    ppl = m.viecap.compute_perplexity(meta["perplexity_sentences"])
+    np.testing.assert_allclose(ppl, g["perplexity"], rtol=5e-4)
+    np.testing.assert_allclose(ppl, orc.compute_perplexity(meta["perplexity_sentences"]), rtol=5e-4)
+    caps2, scores = m.caption_tokens(x.clone().cuda(), compute_scores=True)
+    assert caps2 == caps and len(scores) == len(caps)
+    np.testing.assert_allclose(scores, orc.compute_perplexity(caps), rtol=5e-4)
+    ragged = ["a dog.", "c", " traffic light and a bird on the road", ""]
+    got_r, want_r = m.viecap.compute_perplexity(ragged), orc.compute_perplexity(ragged)
+    for a_, b_ in zip(got_r, want_r):
+        assert (np.isnan(a_) and np.isnan(b_)) or abs(a_ - b_) <= 5e-4 * abs(b_), (got_r, want_r)
 
 
 def test_viecap_soft_prompt_only_and_routing_through_forward(O, case):

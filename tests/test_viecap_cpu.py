@@ -44,6 +44,9 @@ def test_oracle_matches_the_reference_pieces(golden, case):
     assert caps == meta["sentences"]
     one = orc.forward(x[1:2].clone())
     assert isinstance(one, str) and one == meta["single_sentence"]
+    # VieCap.compute_perplexity of the reference on its own sentences (entrypoint.py:155-172)
+    np.testing.assert_allclose(orc.compute_perplexity(meta["perplexity_sentences"]), g["perplexity"], rtol=2e-4)
+    assert np.isnan(orc.compute_perplexity(["c"])[0]) if len(tok.encode("c")) == 1 else True      # one token: mean of nothing
 
 
 def test_mirror_host_logic_matches_the_oracle(case):

@@ -3,7 +3,8 @@
 ``compose_discrete_prompts`` (utils.py:55-74) and ``greedy_search`` (search.py:108-191) wired exactly as ``VieCap.forward``
 wires them (entrypoint.py:98-153, hard prompt, soft prompt first, greedy search: the shipped config), on a
 ``GPT2LMHeadModel(GPT2Config())`` that carries OUR seeded weights (the pretrained 'gpt2' needs network) and OUR seeded
-byte-level BPE vocabulary as the tokenizer object (same reason).  Also a single-feature call (the str-returning path).
+byte-level BPE vocabulary as the tokenizer object (same reason).  Also a single-feature call (the str-returning path) and
+``VieCap.compute_perplexity`` (entrypoint.py:155-172) of the generated sentences.
     python tools/oracle/gen_golden_viecap.py"""
 import json
 import os
@@ -77,6 +78,30 @@ single = viecap_forward(x[1:2].clone())
 assert isinstance(single[4], str)
 meta["single_sentence"] = single[4]
 out["single_decoded_ids"] = np.array(recorded[0], dtype=np.int32)
+# VieCap.compute_perplexity (entrypoint.py:155-172) on the sentences above: the method uses nothing of ``self``
+entry = importlib.import_module("refsrc.viecap.entrypoint")
+
+
+class _Enc(dict):
+    def to(self, device):
+        return self
+
+    def __getattr__(self, k):
+        return self[k]
+
+
+class _CallableTok:
+    """the HF call convention compute_perplexity uses: tokenizer(sentence, return_tensors='pt') -> input_ids, attention_mask"""
+
+    def __call__(self, sentence, return_tensors="pt"):
+        ids = torch.tensor([tok.encode(sentence)], dtype=torch.long)
+        return _Enc(input_ids=ids, attention_mask=torch.ones_like(ids))
+
+
+ppl = entry.VieCap.compute_perplexity(None, sentences, tokenizer=_CallableTok(), model=gpt, device="cpu")
+out["perplexity"] = np.array(ppl, dtype=np.float64)
+meta["perplexity_sentences"] = sentences
+print("perplexities", ppl)
 out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
 path = os.path.join(ROOT, "tests", "golden", "viecap.npz")
 np.savez_compressed(path, **out)
