@@ -15,12 +15,13 @@ d=json.loads(sys.stdin.read())
 print('%-34s value %7.0f  group median %.2f ms p95 %.2f  gemm %.1f us frac %.3f' % ('$label', d['value'], d['pipelined_groups']['ms_per_group']['median'], d['pipelined_groups']['ms_per_group']['p95'], d['roofline']['avg_launch_us'], d['roofline']['frac']))" >> gpurun_out/sweep.log || return 1
 }
 : > gpurun_out/sweep.log
-run "default" -- &&
-run "old gemm" PIO_GEMM256_MIN_TILES=0 -- &&
+run "default (5 per launch, 3 decodes)" -- &&
+run "decodes 2" -- --decode-streams 2 &&
 run "decodes 4" -- --decode-streams 4 &&
 run "decodes 5" -- --decode-streams 5 &&
-run "decodes 6" -- --decode-streams 6 &&
-run "old gemm, decodes 5" PIO_GEMM256_MIN_TILES=0 -- --decode-streams 5 &&
-run "vit-batches 2" -- --vit-batches 2 &&
-run "256 only for wide (min tiles 250)" PIO_GEMM256_MIN_TILES=250 --
+run "4 per launch" -- --vit-batches 4 &&
+run "8 per launch" -- --vit-batches 8 &&
+run "default again" -- &&
+run "old gemm" PIO_GEMM256_MIN_TILES=0 -- &&
+run "old projection" PIO_PROJECT_V1=1 --
 cat gpurun_out/sweep.log
