@@ -424,10 +424,10 @@ __global__ __launch_bounds__(256 * NQG, 1) void k_project2(const float* __restri
       sfull += o;                                                                                              \
     }                                                                                                          \
     float tmax = -INFINITY;                                                                                    \
+    const int rows_left = (int)(M - (t) * PR_ROWS < PR_ROWS ? M - (t) * PR_ROWS : PR_ROWS);   /* 16 but in the bank's last tile */ \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
-      const int64_t row = (t) * PR_ROWS + 4 * kq + i;                                                          \
-      float z = -INFINITY;                                                                                     \
-      if (row < M) z = (sfull[i] * inv4[i]) / temperature;                                                     \
+      float z = (sfull[i] * inv4[i]) / temperature;                                                            \
+      if (4 * kq + i >= rows_left) z = -INFINITY;                                                              \
       p[i] = z;                                                                                                \
       tmax = fmaxf(tmax, z);                                                                                   \
     }                                                                                                          \
@@ -469,10 +469,9 @@ __global__ __launch_bounds__(256 * NQG, 1) void k_project2(const float* __restri
   } while (0)
 #define PIO_LOAD_INV(t)                                                                                        \
   do {                                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
-      const int64_t row = (t) * PR_ROWS + 4 * kq + i;                                                          \
-      inv4[i] = inv_norm[row < M ? row : M - 1];                                                               \
-    }                                                                                                          \
+    const float* _ib = inv_norm + (t) * PR_ROWS;                /* scalar tile base + a 32-bit lane offset */        \
+    const int _last = (int)(M - 1 - (t) * PR_ROWS);                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) inv4[i] = _ib[4 * kq + i < _last ? 4 * kq + i : _last];      \
   } while (0)
 #define PIO_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)   /* vmcnt(0), expcnt / lgkmcnt untouched: known to hipcc's own counting */
 #define PIO_RAW_BARRIER()                                                                                      \
@@ -499,11 +498,10 @@ __global__ __launch_bounds__(256 * NQG, 1) void k_project2(const float* __restri
       const bool more = t + 1 < t_end;
       float inv_next[4];
       if (more) {
+        const float* ib = inv_norm + (t + 1) * PR_ROWS;
+        const int last = (int)(M - 1 - (t + 1) * PR_ROWS);      // >= 0: tile t+1 starts inside the bank
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int64_t row = (t + 1) * PR_ROWS + 4 * kq + i;
-          inv_next[i] = inv_norm[row < M ? row : M - 1];
-        }
+        for (int i = 0; i < 4; ++i) inv_next[i] = ib[4 * kq + i < last ? 4 * kq + i : last];
       }
       PIO_GEMM2(cur);
       PIO_ROWSUM();                     // l_run of tile t, in the shadow of the MFMAs just issued

@@ -37,6 +37,9 @@
 
 namespace pio {
 
+#ifndef PIO_ATTN_OCC          // waves per SIMD k_vit_attention is compiled for: 2 (144 VGPRs, three workgroups per CU in practice);
+#define PIO_ATTN_OCC 2         // 4 = 128 VGPRs with 56 B of scratch, measured: see the file header
+#endif
 static constexpr int KV_TILE = 64;
 static constexpr int KV_TILE_BYTES = KV_TILE * 64 * 2;  // 8 KiB
 
@@ -58,7 +61,7 @@ __device__ __forceinline__ bool attn_block(int nblk, int BH, int& qblk, int& bh)
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void k_vit_attention(const VitAttnArgs a) {
+__global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];  // K0 V0 K1 V1
   typedef typename Vec8<T>::type frag_t;
   typedef typename Vec4<T>::type half4_t;
