@@ -17,21 +17,23 @@
 //                                              is read with the same permutation), so P never visits LDS.
 // The accumulator O^T has the query on the lane as well, so rescaling by exp(m_old - m_new) is lane-local.
 //
-// k_vit_attention (round 1) stays the default; k_vit_attention2 (round 2, PIO_ATTN_V2=1) is a restructuring that was built
-// to the end, is correct (same tests), and is NOT faster -- kept because its measurements say where the time is not:
+// Round 2.  What moved the kernel was its VALU count: on gfx950 another wave's plain VALU instructions do NOT run under an
+// MFMA (tools/microbench/mfma_valu_overlap.hip: 20.4 ms together against 11.4 + 9.7 ms alone; v_exp_f32 does overlap), so the
+// ~250 plain VALU instructions round 1 spent per 16 MFMAs were all MFMA time.  k_vit_attention's softmax is now: padding keys
+// masked only in a sequence's last tile, the scale folded into the exponent's FMA (maximum over raw scores), packed fp32
+// FMA / add, packed conversions, no rescale of O^T while no maximum moved.  64 images: 47.9 us per launch (279 TF) against
+// 51.3; 16 images 19.3 against 20.5; 518^2 x 8: 93 us (497 TF) against 105.
+// k_vit_attention2 (PIO_ATTN_V2=1) is a larger restructuring built before that was understood; correct (same tests), not
+// faster, kept for its measurements:
 //   * workgroup = ceil(nq / ceil(nq / 8)) waves (T = 261: 9 query tiles = two workgroups of 5 waves instead of three of 4
 //     whose third is 6 % full); K / V^T by LDS-DMA through a ring of 2-4 tiles with counted vmcnt (no staging registers, no
-//     ds_write); the softmax on half the VALU instructions (mask only in the last tile, scale folded into the exponent's
-//     FMA, packed fp32 FMA / add / conversions, rescale skipped while no maximum moved, all-padding half tiles skipped).
-//   * 64 images (768 heads), per launch: round 1 52 us; this one 56 / 58 / 61 us with a ring of 2 / 3 / 4 tiles.  16 images:
-//     20.6 vs 20.3 us; 518^2 x 8: 107 vs 104 us.  An XCD-aware block order (both kernels, attn_block below) changed nothing
-//     either.  PMC of this kernel at 64 images (rocprofv3, tools/microbench/attn_run.py): MFMA busy 11 % of the SIMD cycles,
-//     VALU ~35 % (8.5 k instructions per SIMD), LDS index-active 15 % of which 38 % bank conflicts, waves waiting (s_waitcnt /
-//     barrier) 50 % of their resident cycles, 55.8 us at 2.49 GHz.  Neither the VALU count, nor the K / V^T traffic, nor the
-//     load look-ahead bounds it: the three pipes are each lightly used and do not overlap -- every wave runs
-//     read K -> 8 MFMA -> max/exp chain (two lane exchanges) -> read V -> 8 MFMA serially, meets 3-4 others at a barrier per
-//     64 keys, and at 12-15 waves per CU there is not enough independent work to fill the gaps.  What is left to try is
-//     in-wave software pipelining (S^T of tile t+1 issued under the softmax of tile t, +32 VGPRs) with 64 queries per wave.
+//     ds_write); the same lean softmax, all-padding half tiles skipped.
+//   * 64 images: 56 / 58 / 61 us with a ring of 2 / 3 / 4 tiles.  An XCD-aware block order (both kernels, attn_block below)
+//     changed nothing.  PMC at 64 images (rocprofv3, tools/microbench/attn_run.py, profiles/r02_attention_pmc.json): MFMA
+//     busy 11 % of the SIMD cycles, VALU ~35 %, LDS index-active 15 % of which 38 % bank conflicts, waves waiting (s_waitcnt /
+//     barrier) 50 % of their resident cycles.  Every wave runs read K -> 8 MFMA -> max / exp chain (two lane exchanges) ->
+//     read V -> 8 MFMA serially and meets 3-4 others at a barrier per 64 keys; more waves per SIMD do not help (128 VGPRs
+//     spill: 72 us).  Left to try: S^T of tile t+1 issued under the softmax of tile t (+32 VGPRs), 64 queries per wave.
 #include "common.h"
 #include "kernels.h"
 
@@ -43,6 +45,11 @@ namespace pio {
 static constexpr int KV_TILE = 64;
 static constexpr int KV_TILE_BYTES = KV_TILE * 64 * 2;  // 8 KiB
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+template <typename T> struct Vec2;
+template <> struct Vec2<f16> { typedef _Float16 type __attribute__((ext_vector_type(2))); };
+template <> struct Vec2<bf16> { typedef __bf16 type __attribute__((ext_vector_type(2))); };
 template <typename T> struct Vec4;
 template <> struct Vec4<f16> { typedef _Float16 type __attribute__((ext_vector_type(4))); };
 template <> struct Vec4<bf16> { typedef __bf16 type __attribute__((ext_vector_type(4))); };
@@ -148,44 +155,68 @@ __global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAt
           st[kbk] = mfma32(kf, qf[s], st[kbk]);
         }
       }
-      // mask keys >= T, move to the log2 domain, tile max
-      float mx = -1e30f;
+      // the softmax on half the VALU instructions (gfx950 does not overlap another wave's plain VALU with MFMAs -- tools/
+      // microbench/mfma_valu_overlap.hip: 20.4 ms together against 11.4 + 9.7 alone -- so every one of them is MFMA time):
+      // padding keys are masked only in the sequence's last tile; the scale rides in the exponent's FMA (the maximum is
+      // taken over raw scores); packed fp32 FMA / add and packed conversions; no rescale while no query's maximum moved.
+      // (Skipping the all-padding upper half of a sequence's last tile as well costs 4 more VGPRs -- 172, two waves per SIMD
+      // instead of three -- and loses: 53.6 against 47.8 us at 64 images.)
+      const int left = nkeys - kt * KV_TILE;              // keys of the sequence in this tile and after (block-uniform)
+      if (left < KV_TILE) {
 #pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk)
+        for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt * KV_TILE + kbk * 32 + acc_row32(r, lane);
-          const float z = key < nkeys ? st[kbk][r] * sl2 : -1e30f;
-          st[kbk][r] = z;
-          mx = fmaxf(mx, z);
-        }
+          for (int r = 0; r < 16; ++r)
+            if (kbk * 32 + acc_row32(r, lane) >= left) st[kbk][r] = -1e30f;
+      }
+      float mx = st[0][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[0][r]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[1][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      float rs = 0.f;
+      const float m_new = fmaxf(m_run, mx * sl2);
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+        const f32x2 av = {alpha, alpha};
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            f32x2 o = {ot[d][r], ot[d][r + 1]};
+            o *= av;
+            ot[d][r] = o[0]; ot[d][r + 1] = o[1];
+          }
+        m_run = m_new;
+      }
+      const f32x2 sl2v = {sl2, sl2}, mv = {m_run, m_run};
+      f32x2 rs2 = {0.f, 0.f};
+      typedef typename Vec2<T>::type half2_t;
+      half2_t ph[2][8];
 #pragma unroll
       for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(st[kbk][r] - m_new);
-          st[kbk][r] = p;
-          rs += p;
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 sv2 = {st[kbk][r], st[kbk][r + 1]};
+          const f32x2 z = __builtin_elementwise_fma(sv2, sl2v, -mv);
+          f32x2 p;
+          p[0] = __builtin_amdgcn_exp2f(z[0]);
+          p[1] = __builtin_amdgcn_exp2f(z[1]);
+          rs2 += p;
+          ph[kbk][r >> 1] = __builtin_convertvector(p, half2_t);
         }
+      float rs = rs2[0] + rs2[1];
       rs += __shfl_xor(rs, 32);
-      l_run = l_run * alpha + rs;
-      m_run = m_new;
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+      l_run += rs;
       // O^T += V^T . P^T
 #pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk)
+      for (int kbk = 0; kbk < 2; ++kbk) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           frag_t pf;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) pf[j] = (T)st[kbk][8 * s2 + j];
+          for (int j = 0; j < 4; ++j) { pf[2 * j] = ph[kbk][4 * s2 + j][0]; pf[2 * j + 1] = ph[kbk][4 * s2 + j][1]; }
 #pragma unroll
           for (int d = 0; d < 2; ++d) {
             const char* rowp = sv + (d * 32 + r31) * 128 + 8 * h;
@@ -197,6 +228,7 @@ __global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAt
             ot[d] = mfma32(vf, pf, ot[d]);
           }
         }
+      }
     }
     PIO_STORE_KV(buf ^ 1);   // harmless on the last iteration: that buffer is not read again
     __syncthreads();
@@ -223,11 +255,6 @@ __global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAt
 }
 
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-template <typename T> struct Vec2;
-template <> struct Vec2<f16> { typedef _Float16 type __attribute__((ext_vector_type(2))); };
-template <> struct Vec2<bf16> { typedef __bf16 type __attribute__((ext_vector_type(2))); };
 
 // blockDim.x = 64 * (waves per workgroup, 1..8); grid = (query blocks, B * H).
 // K / V^T tiles stream through a ring of ATT_RING tiles (16 KiB each): the prologue puts ATT_RING tiles in flight, the
