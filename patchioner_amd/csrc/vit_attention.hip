@@ -33,7 +33,16 @@
 //     busy 11 % of the SIMD cycles, VALU ~35 %, LDS index-active 15 % of which 38 % bank conflicts, waves waiting (s_waitcnt /
 //     barrier) 50 % of their resident cycles.  Every wave runs read K -> 8 MFMA -> max / exp chain (two lane exchanges) ->
 //     read V -> 8 MFMA serially and meets 3-4 others at a barrier per 64 keys; more waves per SIMD do not help (128 VGPRs
-//     spill: 72 us).  Left to try: S^T of tile t+1 issued under the softmax of tile t (+32 VGPRs), 64 queries per wave.
+//     spill: 72 us).
+// A third form was built and removed again (round 2, same tests green): one PERSISTENT workgroup per CU, the whole K / V^T of
+// a head resident in LDS (T <= 320: 80 KiB) and double-buffered across heads (2 x 80 KiB), one wave per query tile, ONE
+// barrier per head, no load and no barrier in the key loop.  Its ablations at 64 images say where the time is: loading
+// Q / K / V^T 16.5 us, the key loop 32 us, storing O 7-9 us; un-overlapped (one head per workgroup) they add up to 55 us,
+// overlapped (persistent) to 48.1 us -- exactly this kernel's 47.9.  The key loop is ISSUE-bound: ~1 700 cycles per (32
+// queries x 64 keys) = 512 of MFMA + ~200 plain VALU instructions (80 of them v_mov: hipcc pairs the two 8-byte V^T pieces of
+// two rows in one ds_read2st64_b64 and then regroups them) that do not run under MFMAs; 120 MB of Q / K / V / O per launch
+// put the memory floor at ~24 us.  What would move it: V^T stored in LDS in the order the P^T fragment needs (one b128 read,
+// no moves), S^T of tile t+1 issued under the softmax of tile t, fewer VALU instructions still.
 #include "common.h"
 #include "kernels.h"
 
