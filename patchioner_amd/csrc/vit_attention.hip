@@ -104,11 +104,18 @@ __global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAt
 
   // staging assignment: 2 chunks of K and 2 of V^T per thread per tile
   const int kc = tid & 7, row0 = tid >> 3;   // rows row0, row0+32
-  int lds_off[2];
+  // K rows keep their 16-B chunks in place (chunk ^ swizzle(row)).  A V^T row is stored in the order the P^T fragment wants
+  // it: lane-half h of k-step g (16 keys) multiplies keys {16g + 4h .. +3, 16g + 8 + 4h .. +3} -- the low (h = 0) or high 8
+  // bytes of chunks 2g and 2g + 1 -- so slot 2g + h holds [that half of chunk 2g | that half of chunk 2g + 1] and the
+  // fragment is ONE ds_read_b128 (it was two 8-byte pieces that hipcc fetched pairwise across rows and regrouped with
+  // v_movs, which are MFMA time on gfx950).  Costs two ds_write_b64 instead of one b128 per staged chunk.
+  int lds_off[2], lds_off_v[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int row = row0 + 32 * i;
-    lds_off[i] = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
+    const int row = row0 + 32 * i, swz = (row >> 1) & 7;
+    lds_off[i] = row * 128 + ((kc ^ swz) << 4);
+    lds_off_v[i][0] = row * 128 + ((((kc & ~1) + 0) ^ swz) << 4) + (kc & 1) * 8;
+    lds_off_v[i][1] = row * 128 + ((((kc & ~1) + 1) ^ swz) << 4) + (kc & 1) * 8;
   }
   // staging registers: plain named values (arrays captured by lambdas end up in scratch)
   uint4 rk0, rk1, rv0, rv1;
@@ -129,8 +136,10 @@ __global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAt
     char* _sv = _sk + KV_TILE_BYTES;                                    \
     *(uint4*)(_sk + lds_off[0]) = rk0;                                  \
     *(uint4*)(_sk + lds_off[1]) = rk1;                                  \
-    *(uint4*)(_sv + lds_off[0]) = rv0;                                  \
-    *(uint4*)(_sv + lds_off[1]) = rv1;                                  \
+    *(uint2*)(_sv + lds_off_v[0][0]) = make_uint2(rv0.x, rv0.y);        \
+    *(uint2*)(_sv + lds_off_v[0][1]) = make_uint2(rv0.z, rv0.w);        \
+    *(uint2*)(_sv + lds_off_v[1][0]) = make_uint2(rv1.x, rv1.y);        \
+    *(uint2*)(_sv + lds_off_v[1][1]) = make_uint2(rv1.z, rv1.w);        \
   } while (0)
 
   const int sw7 = (lane >> 1) & 7;
@@ -228,12 +237,7 @@ __global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAt
           for (int j = 0; j < 4; ++j) { pf[2 * j] = ph[kbk][4 * s2 + j][0]; pf[2 * j + 1] = ph[kbk][4 * s2 + j][1]; }
 #pragma unroll
           for (int d = 0; d < 2; ++d) {
-            const char* rowp = sv + (d * 32 + r31) * 128 + 8 * h;
-            const half4_t lo = *(const half4_t*)(rowp + (((4 * kbk + 2 * s2) ^ sw7) << 4));
-            const half4_t hi = *(const half4_t*)(rowp + (((4 * kbk + 2 * s2 + 1) ^ sw7) << 4));
-            frag_t vf;
-            vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-            vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+            const frag_t vf = *(const frag_t*)(sv + (d * 32 + r31) * 128 + (((4 * kbk + 2 * s2 + h) ^ sw7) << 4));
             ot[d] = mfma32(vf, pf, ot[d]);
           }
         }
