@@ -21,8 +21,9 @@
 // MFMA (tools/microbench/mfma_valu_overlap.hip: 20.4 ms together against 11.4 + 9.7 ms alone; v_exp_f32 does overlap), so the
 // ~250 plain VALU instructions round 1 spent per 16 MFMAs were all MFMA time.  k_vit_attention's softmax is now: padding keys
 // masked only in a sequence's last tile, the scale folded into the exponent's FMA (maximum over raw scores), packed fp32
-// FMA / add, packed conversions, no rescale of O^T while no maximum moved.  64 images: 47.9 us per launch (279 TF) against
-// 51.3; 16 images 19.3 against 20.5; 518^2 x 8: 93 us (497 TF) against 105.
+// FMA / add, packed conversions, no rescale of O^T while no maximum moved; and a V^T row sits in LDS in the order the P^T
+// fragment multiplies it (one ds_read_b128 per fragment, no regrouping v_movs).  64 images: 46.1 us per launch (290 TF)
+// against round 1's 51.3; 16 images 18.4 against 20.5; 518^2 x 8: 86 us (537 TF) against 105.
 // k_vit_attention2 (PIO_ATTN_V2=1) is a larger restructuring built before that was understood; correct (same tests), not
 // faster, kept for its measurements:
 //   * workgroup = ceil(nq / ceil(nq / 8)) waves (T = 261: 9 query tiles = two workgroups of 5 waves instead of three of 4
