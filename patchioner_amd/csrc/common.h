@@ -44,6 +44,26 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// x combined with the lanes 16 / 32 away, without the LDS crossbar (ds_bpermute, ~130 cycles on a serial chain): gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange rows / halves between two registers; fed (x, x) they return (own-or-partner,
+// partner-or-own), and max / + are commutative, so the result is bit-identical to x op __shfl_xor(x, 16 | 32).
+__device__ __forceinline__ float xor16_max(float x) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor16_add(float x) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_add(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // GELU(v) = 0.5 v (1 + erf(v / sqrt 2)), the exact-erf form DINOv2's MLP uses, to 7.5e-7 absolute (fp32 evaluation,
 // checked against scipy on [-12, 12]; the result is rounded to fp16/bf16 anyway).  erfc(t) = 2^(-t q(t)) with a degree-5
 // polynomial q fitted on [0, 4.3] (least squares weighted for the absolute error of erf; erfc(4.3) = 1.2e-9).  With

@@ -260,26 +260,6 @@ __global__ __launch_bounds__(256 * NQG, NQG == 1 ? 2 : 1) void k_project(const f
   }
 }
 
-// x combined with the lanes 16 / 32 away, without the LDS crossbar (ds_bpermute, ~130 cycles on a serial chain): gfx950's
-// v_permlane16_swap / v_permlane32_swap exchange rows / halves between two registers; fed (x, x) they return (own-or-partner,
-// partner-or-own), and max / + are commutative, so the result is bit-identical to x op __shfl_xor(x, 16 | 32).
-__device__ __forceinline__ float xor16_max(float x) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float xor32_max(float x) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float xor16_add(float x) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float xor32_add(float x) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
 // ---- round 2: the same pass, software-pipelined -------------------------------------------------------------------
 // k_project spends a 16-row tile as  [GEMM1 -> partial S to LDS] barrier [sum, soft-max, GEMM2] barrier [registers -> LDS]
 // barrier: three barriers, a register-staged single buffer, and the MFMA pipe idle around each of them (PMC: 39-49 % busy;

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAt
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[0][r]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[1][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = xor32_max(mx);                                // v_permlane32_swap: no LDS crossbar round trip on the chain
       const float m_new = fmaxf(m_run, mx * sl2);
       if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAt
           ph[kbk][r >> 1] = __builtin_convertvector(p, half2_t);
         }
       float rs = rs2[0] + rs2[1];
-      rs += __shfl_xor(rs, 32);
+      rs = xor32_add(rs);
       l_run += rs;
       // O^T += V^T . P^T
 #pragma unroll
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(512, 4) void k_vit_attention2(const VitAttnArgs a) 
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[0][r]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[1][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = xor32_max(mx);                                // v_permlane32_swap: no LDS crossbar round trip on the chain
       const float m_new = fmaxf(m_run, mx * sl2);
       if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {   // some query's running maximum moved: rescale
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512, 4) void k_vit_attention2(const VitAttnArgs a) 
           ph[kbk][r >> 1] = __builtin_convertvector(p, half2_t);
         }
       float rs = rs2[0] + rs2[1];
-      rs += __shfl_xor(rs, 32);
+      rs = xor32_add(rs);
       l_run += rs;
       // O^T += V^T . P^T
 #pragma unroll
