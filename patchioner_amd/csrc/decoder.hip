@@ -50,6 +50,9 @@ namespace pio {
 #ifndef PIO_LMF16_DEEP        // 64 / 128 prefixes: three X~ / weight chunks in flight instead of one / two (measured: 56.6 vs 50.3 us, off)
 #define PIO_LMF16_DEEP 0
 #endif
+#ifndef PIO_LMF16_WAVES8      // waves per workgroup of k_lmhead_f16 at 128 prefixes (4 = round 1)
+#define PIO_LMF16_WAVES8 8
+#endif
 #ifndef PIO_LMF16_ABL         // timing ablations of k_lmhead_f16 (diagnostic builds only): 1 no epilogue, 2 no X~ DMA, 3 no MFMA
 #define PIO_LMF16_ABL 0
 #endif
@@ -1000,8 +1003,8 @@ __global__ __launch_bounds__(256) void k_lm_prep(const float* __restrict__ x, in
   }
 }
 
-template <int RG>
-__global__ __launch_bounds__(256, 2) void k_lmhead_f16(const uint16_t* __restrict__ W16, const _Float16* __restrict__ Xh, int N, int V,
+template <int RG, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_lmhead_f16(const uint16_t* __restrict__ W16, const _Float16* __restrict__ Xh, int N, int V,
                                                        int Vp, const float* __restrict__ stats, const float* __restrict__ dvec,
                                                        const float* __restrict__ cvec, float w_unscale, float* __restrict__ out,
                                                        float* __restrict__ gmax, int NGp) {
@@ -1010,16 +1013,16 @@ __global__ __launch_bounds__(256, 2) void k_lmhead_f16(const uint16_t* __restric
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
-  const int blk = blockIdx.x * 4 + wid;
+  const int blk = blockIdx.x * NWV + wid;
   const int j = blk * 16 + li;
   const int jc = j < V ? j : V - 1;
   const uint16_t* wp = W16 + (size_t)jc * K + 8 * kq;
-  // LDS-DMA pieces of an X~ chunk: 1 KiB = 8 rows x 128 B; pieces wid, wid + 4, ...
-  constexpr int NP = ROWS / 8, PPW = (NP + 3) / 4;
+  // LDS-DMA pieces of an X~ chunk: 1 KiB = 8 rows x 128 B; pieces wid, wid + NWV, ...
+  constexpr int NP = ROWS / 8, PPW = (NP + NWV - 1) / NWV;
   uint32_t xoff[PPW];
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
-    const int row = 8 * (wid + 4 * i) + (lane >> 3);
+    const int row = 8 * (wid + NWV * i) + (lane >> 3);
     const int rc = row < N ? row : N - 1;
     xoff[i] = ((uint32_t)rc * K) * 2 + 16 * ((lane & 7) ^ ((row >> 1) & 7));
   }
@@ -1027,9 +1030,9 @@ __global__ __launch_bounds__(256, 2) void k_lmhead_f16(const uint16_t* __restric
 #define PIO_XISSUE(q, buf)                                                                                     \
   do {                                                                                                         \
     _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                          \
-      if (PIO_LMF16_ABL != 2 && (NP % 4 == 0 || wid + 4 * i < NP)) {                                           \
+      if (PIO_LMF16_ABL != 2 && (NP % NWV == 0 || wid + NWV * i < NP)) {                                           \
         const char* _g = (const char*)Xh + (q) * (CH * 2) + xoff[i];                                           \
-        const uint32_t _l = lds0 + (uint32_t)((buf) * XB + i * 4096);                                          \
+        const uint32_t _l = lds0 + (uint32_t)((buf) * XB + i * NWV * 1024);                                          \
         uint32_t _keep;                                                                                        \
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
                      : "=&s"(_keep) : "v"(_g), "s"(_l) : "memory");                                            \
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(256, 2) void k_lmhead_f16(const uint16_t* __restric
   // DEPTH + 1 buffers and weight sets, DEPTH chunks in flight.  Every wave issues PPW pieces per chunk there (NP % 4 == 0).
   constexpr bool DEEP = PIO_LMF16_DEEP != 0 && RG >= 4;
   constexpr int DEPTH = DEEP ? 3 : 1, NSET = DEEP ? DEPTH + 1 : 3;
-  static_assert(!DEEP || NP % 4 == 0, "uniform vm queue");
+  static_assert(!DEEP || NP % NWV == 0, "uniform vm queue");
   f32x4 w[NSET][2];
   f32x4 acc[RG];
 #pragma unroll
@@ -1327,16 +1330,19 @@ __global__ __launch_bounds__(256) void k_dec_select_filter(const float* __restri
 
 template <int RG>
 static hipError_t launch_lmhead_f16(const DecoderArgs& a, hipStream_t s) {
+  // 128 prefixes (RG = 8): 8 waves = 128 columns per workgroup share an X~ chunk, halving the X~ reads through L2 (77 instead of
+  // 154 MB per step); fewer row groups keep 4 waves (two workgroups per CU cover each other's chunk waits)
+  constexpr int NWV = RG >= 8 ? PIO_LMF16_WAVES8 : 4;
   const int Vp = round_up(a.vocab, 64);
   const int smem = (PIO_LMF16_DEEP != 0 && RG >= 4 ? 4 : 2) * RG * 16 * 64 * 2;
   const int NGp = round_up(ceil_div(a.vocab, 16), 64);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_lmhead_f16<RG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)k_lmhead_f16<RG, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_lmhead_f16<RG>), dim3(ceil_div(a.vocab, 64)), dim3(256), smem, s, a.head_w16, (const _Float16*)a.xh, a.N,
+  hipLaunchKernelGGL((k_lmhead_f16<RG, NWV>), dim3(ceil_div(a.vocab, 16 * NWV)), dim3(64 * NWV), smem, s, a.head_w16, (const _Float16*)a.xh, a.N,
                      a.vocab, Vp, a.lm_stats, a.head_d, a.head_c, a.head_w16_unscale, a.logits,
                      a.lm_gmax, NGp);
   return hipGetLastError();
