@@ -81,12 +81,7 @@ def test_config4_capdec_dense_boxes_chunked(O):
     want = orc.forward(imgs.clone(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=0.5)
     assert len(sum(got["bbox_capts"], [])) == len(sum(want["bbox_capts"], [])) == B * NB
     assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "config4 (CapDec, dense boxes)")
-    # decoder stage alone on identical prefixes: bit-exact ids for all 144 prefixes
-    tokens, _ = m.engine.vit_forward(imgs)
-    feats = m._bbox_feats(tokens, boxes.clone(), True, 0.5, False, None).view(-1, 768)
-    ids, _ = m.engine.decode_greedy(feats)
-    ref_ids, _, margin = O.DeCapOracle(W.synth_decap(3)).decode_ids(feats.cpu())
-    assert np.array_equal(ids.cpu().numpy(), ref_ids.numpy()), "min margin %.2e" % float(margin.min())
+    # (the decoder stage alone on identical prefixes, bit-exact for all 144, is clause (1) of assert_ids_explained above)
     # config 4's multi-GPU driver on the real model (no process group = one shard; the 2-rank sharding itself is tested with
     # gloo in tests/test_dist_cpu.py): nested [B][NB] captions of the forward, the caller's boxes floor-divided in place
     from patchioner_amd import dist as pdist
@@ -361,11 +356,10 @@ def test_caption_bboxes_crop_and_recaption_vs_oracle(O):
     m = _model(224, True, max_batch=4)
     orc = _oracle_for(O, 224, True)
     rng = np.random.RandomState(21)
-    sizes = [(320, 240), (200, 333), (500, 375)]
+    sizes = [(320, 240), (200, 333)]
     imgs = [Image.fromarray(rng.randint(0, 256, size=(h, w, 3), dtype=np.uint8)) for w, h in sizes]
-    boxes = torch.tensor([[[10.0, 20.0, 150.0, 100.0], [0.0, 0.0, 320.0, 240.0], [100.5, 60.25, 80.0, 120.75], [300.0, 200.0, 60.0, 80.0]],
-                          [[5.0, 5.0, 100.0, 300.0], [50.0, 100.0, 140.0, 60.0], [0.0, 0.0, 30.0, 30.0], [150.0, 250.0, 50.0, 83.0]],
-                          [[0.0, 0.0, 499.0, 374.0], [250.0, 100.0, 200.0, 200.0], [20.0, 300.0, 460.0, 70.0], [400.0, 10.0, 150.0, 90.0]]])
+    boxes = torch.tensor([[[10.0, 20.0, 150.0, 100.0], [0.0, 0.0, 320.0, 240.0], [100.5, 60.25, 80.0, 120.75]],     # inside, whole image, fractional
+                          [[5.0, 5.0, 100.0, 300.0], [0.0, 0.0, 30.0, 30.0], [150.0, 250.0, 50.0, 83.0]]])          # tall, tiny, touching the border
     for crop_boxes in (False, True):
         tf = m.image_transforms if crop_boxes else m.image_transforms_no_crop
         crops = process_bboxes(imgs, boxes, tf)
