@@ -73,7 +73,17 @@ def cpu_baseline():
     from patchioner_amd import weights as W
     from patchioner_amd.tokenizer import ClipDetokenizer
     torch.set_grad_enabled(False)
+    # the threads this process can really run: a GPU box shows 256 CPUs but its cgroup grants 16 -- torch's default of 128
+    # threads is then throttled (the same step takes 2-6x longer) and "cores: 128" would be a fiction
     cores = torch.get_num_threads()
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(quota) // int(period)))
+    except (AttributeError, OSError, ValueError):
+        pass
+    torch.set_num_threads(cores)
     vit = O.DinoV2Oracle(W.synth_dinov2(1), num_heads=12)
     dec = O.DeCapOracle(W.synth_decap(3))
     bank = W.synth_bank(6, BANK_ROWS)

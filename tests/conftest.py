@@ -11,8 +11,31 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: the cgroup quota (a GPU box shows 256 CPUs and grants 16: torch's default of
+    128 threads then spends its time being throttled -- one oracle-heavy test took 48 s with 128 threads and 7 s with 16),
+    the affinity mask, the CPU count, whichever is smallest."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:
+        import torch
+        torch.set_num_threads(min(torch.get_num_threads(), usable_cpus()))
+    except ImportError:
+        pass
 
 
 @pytest.fixture(scope="session")
