@@ -356,10 +356,11 @@ def test_caption_bboxes_crop_and_recaption_vs_oracle(O):
     m = _model(224, True, max_batch=4)
     orc = _oracle_for(O, 224, True)
     rng = np.random.RandomState(21)
-    sizes = [(320, 240), (200, 333)]
+    sizes = [(320, 240), (200, 333), (500, 375)]
     imgs = [Image.fromarray(rng.randint(0, 256, size=(h, w, 3), dtype=np.uint8)) for w, h in sizes]
-    boxes = torch.tensor([[[10.0, 20.0, 150.0, 100.0], [0.0, 0.0, 320.0, 240.0], [100.5, 60.25, 80.0, 120.75]],     # inside, whole image, fractional
-                          [[5.0, 5.0, 100.0, 300.0], [0.0, 0.0, 30.0, 30.0], [150.0, 250.0, 50.0, 83.0]]])          # tall, tiny, touching the border
+    boxes = torch.tensor([[[10.0, 20.0, 150.0, 100.0], [0.0, 0.0, 320.0, 240.0], [100.5, 60.25, 80.0, 120.75], [300.0, 200.0, 60.0, 80.0]],
+                          [[5.0, 5.0, 100.0, 300.0], [50.0, 100.0, 140.0, 60.0], [0.0, 0.0, 30.0, 30.0], [150.0, 250.0, 50.0, 83.0]],
+                          [[0.0, 0.0, 499.0, 374.0], [250.0, 100.0, 200.0, 200.0], [20.0, 300.0, 460.0, 70.0], [400.0, 10.0, 150.0, 90.0]]])
     for crop_boxes in (False, True):
         tf = m.image_transforms if crop_boxes else m.image_transforms_no_crop
         crops = process_bboxes(imgs, boxes, tf)
