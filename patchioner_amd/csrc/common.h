@@ -84,6 +84,33 @@ __device__ __forceinline__ float gelu_erf(float v) {
   return fmaxf(v, 0.f) - fabsf(h);
 }
 
+// gelu_erf on two values at once: the polynomial and the final product as packed fp32 FMAs / multiplies (v_pk_fma_f32: two
+// IEEE FMAs per instruction, so each component is bit-identical to gelu_erf).  The fc1 epilogue evaluates 64 Ki of these per
+// tile and is VALU-bound.
+typedef float pio_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pio_f32x2 gelu_erf2(pio_f32x2 v) {
+  pio_f32x2 u;
+  u[0] = fminf(fabsf(v[0]), 6.0811183f);
+  u[1] = fminf(fabsf(v[1]), 6.0811183f);
+  const pio_f32x2 c5 = {-1.971039006e-05f, -1.971039006e-05f}, c4 = {6.613329563e-04f, 6.613329563e-04f};
+  const pio_f32x2 c3 = {-7.757447031e-03f, -7.757447031e-03f}, c2 = {5.296219534e-02f, 5.296219534e-02f};
+  const pio_f32x2 c1 = {4.590671448e-01f, 4.590671448e-01f}, c0 = {1.151118979e+00f, 1.151118979e+00f}, one = {1.0f, 1.0f};
+  pio_f32x2 q = __builtin_elementwise_fma(c5, u, c4);
+  q = __builtin_elementwise_fma(q, u, c3);
+  q = __builtin_elementwise_fma(q, u, c2);
+  q = __builtin_elementwise_fma(q, u, c1);
+  q = __builtin_elementwise_fma(q, u, c0);
+  const pio_f32x2 e = __builtin_elementwise_fma(u, q, one);
+  pio_f32x2 x;
+  x[0] = __builtin_amdgcn_exp2f(-e[0]);
+  x[1] = __builtin_amdgcn_exp2f(-e[1]);
+  const pio_f32x2 h = v * x;
+  pio_f32x2 r;
+  r[0] = fmaxf(v[0], 0.f) - fabsf(h[0]);
+  r[1] = fmaxf(v[1], 0.f) - fabsf(h[1]);
+  return r;
+}
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
