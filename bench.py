@@ -3,6 +3,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work for N > 1: started without a torch.distributed.run environment, ``bench.py --gpus N`` spawns its N ranks
+itself (fresh child processes through ``python -m torch.distributed.run``, before anything in the parent touches the GPU)
+and exits with their code.
+
 One "step" = one Patchioner.forward over one batch of 16 synthetic 224x224 images with one 16-patch trace
 region per image (caption_from=patches): ViT-B/14-reg (12 layers) -> CLS-attention read-out -> trace grids
 + weighted mean -> memory projection against the 591 753 x 768 bank -> 30-step greedy decode -> id->string.
@@ -119,6 +123,59 @@ def cpu_baseline():
                                              % ", ".join("%.1f" % t for t in t_c1)}}
 
 
+def self_launch(n_gpus: int) -> int:
+    """``python bench.py --gpus N`` without a torch.distributed.run environment: start the N ranks as FRESH child processes
+    (one per GPU) and return their exit code.  Nothing in this parent has touched the GPU (importing torch does not), and
+    the parent never replaces itself: it waits for the child and propagates its code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args) -> None:
+    """PIO_BENCH_DRY=1: the N > 1 control path with no GPU work (gloo on the CPU): rendezvous, the barriers around the timed
+    region, the per-step id all-gather, the MAX-over-ranks time and rank 0's ONE JSON line.  Used by tests/test_bench_launch_cpu.py
+    to cover the self-launch path in a container without a GPU."""
+    from patchioner_amd import dist as pdist
+    import torch.distributed as dist
+    os.environ.setdefault("PIO_DIST_BACKEND", "gloo")
+    rank, world, _ = pdist.init_from_env("gloo")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("PIO_BENCH_DRY_FAIL") == "1" and rank == world - 1:
+        raise SystemExit(3)                                   # test hook: a failing rank must fail the whole command
+    ids = None
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.warmup + args.steps):
+        mine = torch.full((BATCH, 30), rank * 1000 + k, dtype=torch.int32)
+        ids = pdist.all_gather_equal_ids(mine)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    assert ids.shape == (BATCH * world, 30) and all(int(ids[BATCH * r, 0]) // 1000 == r for r in range(world))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work): control path of bench.py --gpus N", "value": BATCH * world * args.steps / dt,
+                          "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry": True,
+                          "scaling": "weak", "higher_is_better": True}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,10 +196,15 @@ def main():
                     help="mode=group: consecutive bs-16 batches that share one ViT launch (1 = a launch per batch)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:     # the driver's plain `python bench.py --gpus N`
+        raise SystemExit(self_launch(args.gpus))
+    if os.environ.get("PIO_BENCH_DRY") == "1":
+        return dry_run(args)
+
     from patchioner_amd import dist as pdist
     rank, world, local = pdist.init_from_env("nccl" if args.gpus > 1 else None)
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (torch.distributed.run started with another --nproc-per-node)" % (args.gpus, world))
     if os.environ.get("PIO_DIST_SHARE_DEVICE") == "1":      # rehearsal of the N > 1 code path on a one-GPU box (with PIO_DIST_BACKEND=gloo)
         local = 0
     torch.cuda.set_device(local)

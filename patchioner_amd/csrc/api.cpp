@@ -120,7 +120,12 @@ struct pio_context {
   float* prompt_buf = nullptr;                    // [max_prefixes][max_steps][E]
   int32_t* tok_buf = nullptr;                     // [max_prefixes][max_steps]
   struct PKey { int N, P, steps; bool operator<(const PKey& o) const { return N != o.N ? N < o.N : (P != o.P ? P < o.P : steps < o.steps); } };
-  std::map<PKey, hipGraphExec_t> pgraphs;
+  // prompted-decode graphs, keyed by (rows, prompt positions, steps).  The prompt length follows the hard prompt of every batch,
+  // so a long run meets many keys: the cache is a small LRU (a graph is ~ (P + steps) x 60 kernel nodes) and evicted execs are destroyed.
+  struct PGraph { hipGraphExec_t exec; uint64_t last_use; };
+  std::map<PKey, PGraph> pgraphs;
+  uint64_t pgraph_clock = 0;
+  static constexpr size_t kMaxPGraphs = 12;
   // memory bank
   float* bank = nullptr; float* bank_inv = nullptr; int64_t bank_rows = 0; int bank_dim = 0;
   float *part_acc = nullptr, *part_ml = nullptr, *sims = nullptr;
@@ -663,7 +668,7 @@ int pio_destroy(pio_handle c) {
   (void)hipSetDevice(c->cfg.device);
   (void)hipDeviceSynchronize();
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
-  for (auto& g : c->pgraphs) (void)hipGraphExecDestroy(g.second);
+  for (auto& g : c->pgraphs) (void)hipGraphExecDestroy(g.second.exec);
   for (void* p : c->allocs) (void)hipFree(p);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto& sl : c->prep_slots) {
@@ -745,9 +750,11 @@ int pio_set_memory_bank(pio_handle c, const float* host_bank, int64_t rows, int3
   keep.reserve(rows);
   for (int64_t r = 0; r < rows; ++r) {
     const float* p = host_bank + r * dim;
-    bool nz = false;
-    for (int d = 0; d < dim && !nz; ++d) nz = p[d] != 0.f;
-    if (nz) keep.push_back(r);
+    // the reference's predicate is on the fp32 NORM (embs.norm(dim=-1) != 0), not on the elements: a row of tiny values
+    // whose squares underflow is dropped too, exactly as on the device path (engine.py: bank.norm(dim=-1) != 0)
+    float ss = 0.f;
+    for (int d = 0; d < dim; ++d) ss += p[d] * p[d];
+    if (std::sqrt(ss) != 0.f) keep.push_back(r);
   }
   const int64_t kept = (int64_t)keep.size();
   if (kept == 0) return fail(PIO_ERR_SHAPE, "memory bank has no non-zero row");
@@ -1158,9 +1165,18 @@ int pio_viecap_decode(pio_handle c, const float* cont, const int32_t* tokens, in
       hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       HIP_OK(ie);
-      it = c->pgraphs.emplace(key, exec).first;
+      if (c->pgraphs.size() >= pio_context::kMaxPGraphs) {       // evict the least recently used graph
+        auto old = c->pgraphs.begin();
+        for (auto jt = c->pgraphs.begin(); jt != c->pgraphs.end(); ++jt)
+          if (jt->second.last_use < old->second.last_use) old = jt;
+        HIP_OK(hipStreamSynchronize(s));                         // it may still be running on the caller's stream
+        (void)hipGraphExecDestroy(old->second.exec);
+        c->pgraphs.erase(old);
+      }
+      it = c->pgraphs.emplace(key, pio_context::PGraph{exec, 0}).first;
     }
-    HIP_OK(hipGraphLaunch(it->second, s));
+    it->second.last_use = ++c->pgraph_clock;
+    HIP_OK(hipGraphLaunch(it->second.exec, s));
   } else {
     HIP_OK(launch_decode_prompted(a, c->prompt_buf, P, s));
   }
