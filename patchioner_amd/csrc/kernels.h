@@ -37,6 +37,9 @@ hipError_t launch_vit_gemm(OperandType t, GemmEpilogue epi, const GemmArgs& a, h
 // 256 x 256 tiles, 8 waves (vit_gemm256.hip): same arithmetic per output element; launch_vit_gemm dispatches to it
 bool vit_gemm256_fits(GemmEpilogue epi, const GemmArgs& a);
 hipError_t launch_vit_gemm256(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
+// persistent 256 x 256 workgroups with a rolling epilogue (vit_gemm_roll.hip): qkv without capture and fc1 at many tiles per CU
+bool vit_gemm_roll_fits(GemmEpilogue epi, const GemmArgs& a);
+hipError_t launch_vit_gemm_roll(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
 
 struct VitAttnArgs {
   const void* q; const void* k; const void* vT;  // as written by EPI_QKV

@@ -374,7 +374,19 @@ static bool gemm256_wanted(GemmEpilogue epi, const GemmArgs& a) {
   return true;
 }
 
+// The persistent kernel with the rolling epilogue (vit_gemm_roll.hip) takes qkv (without the fp32 capture) and fc1 once every
+// CU gets about three tiles: 747 / 996 tiles at 80 images 77.2 vs 81.7 and 112.3 vs 116.3 us, a tie at 64 images (594 / 792
+// tiles), slower below (profiles/r03_gemm_microbench.log).  Same arithmetic per output element.  PIO_GEMM_ROLL_MIN_TILES
+// overrides the threshold (0 = never).
+static int gemm_roll_min_tiles() {
+  static const int v = [] { const char* e = getenv("PIO_GEMM_ROLL_MIN_TILES"); return e ? atoi(e) : 704; }();
+  return v;
+}
+
 hipError_t launch_vit_gemm(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
+  if (gemm_roll_min_tiles() > 0 && a.M > 0 && a.N % 256 == 0 && ceil_div(a.M, 256) * (a.N / 256) >= gemm_roll_min_tiles() &&
+      vit_gemm_roll_fits(epi, a))
+    return launch_vit_gemm_roll(t, epi, a, s);
   if (gemm256_min_tiles() > 0 && a.M > 0 && a.N % 256 == 0 && gemm256_wanted(epi, a) && vit_gemm256_fits(epi, a))
     return launch_vit_gemm256(t, epi, a, s);
   if (a.M <= 0 || a.N % BN != 0 || a.K % (2 * BK) != 0 || a.lda % 8 != 0) return hipErrorInvalidValue;

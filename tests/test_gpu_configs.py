@@ -418,3 +418,27 @@ def test_argmax_text_and_n_best_sims_from_the_h5_bank(O):
     assert all(len(s) == 2 and s[0] >= s[1] for r in out["bbox_sims"] for s in r)
     with pytest.raises(ValueError):
         _model(224, True, max_batch=2)(imgs, return_n_best_sims=2)    # not a calculate_argmax_text model
+
+
+def test_vit_80_images_per_launch_rolling_gemm_is_bitwise_the_16_image_launches():
+    """One ViT launch of 80 images sends qkv / fc1 (747 / 996 tiles of 256^2) to the persistent kernel with the rolling
+    epilogue (vit_gemm_roll.hip) and proj / fc2 to k_vit_gemm256; 16-image launches use the 128- and 256-tile kernels.
+    Every kernel computes an output element with the same arithmetic, so the tokens and the captured qkv are the same BITS
+    whatever a launch holds -- the property the pipeline's shared ViT launches rely on.  Depth 3: middle blocks (rolling
+    qkv) and the last block (qkv with the fp32 capture, the 256 kernel)."""
+    from patchioner_amd.engine import Engine
+    sd = W.synth_dinov2(17, depth=3)
+    big = Engine(embed_dim=768, depth=3, num_heads=12, num_registers=4, crop_dim=224, max_batch=80, vit_dtype="fp16")
+    small = Engine(embed_dim=768, depth=3, num_heads=12, num_registers=4, crop_dim=224, max_batch=16, vit_dtype="fp16")
+    for e in (big, small):
+        e.load_state_dict(sd)
+        e.finalize()
+    imgs = W.synth_images(5, 80, 224).cuda()
+    tok_b, qkv_b = big.vit_forward(imgs)
+    tok_s, qkv_s = small.vit_forward(imgs)
+    torch.cuda.synchronize()
+    assert torch.isfinite(tok_b).all()
+    assert torch.equal(tok_b, tok_s) and torch.equal(qkv_b, qkv_s)
+    tok_b2, _ = big.vit_forward(imgs)                 # and the same bits again (a race would not reproduce)
+    assert torch.equal(tok_b, tok_b2)
+    big.close(); small.close()

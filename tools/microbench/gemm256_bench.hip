@@ -5,8 +5,10 @@
 //        with and without the fp32 qkv capture, a ragged last tile);  time: interleaved rounds, random operands.
 #define PIO_G256_ALL_VARIANTS 1
 #define PIO_G256_STAMPS 1
+#define PIO_ROLL_STAMPS 1
 #include "../../patchioner_amd/csrc/vit_gemm.hip"
 #include "../../patchioner_amd/csrc/vit_gemm256.hip"
+#include "../../patchioner_amd/csrc/vit_gemm_roll.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -97,9 +99,11 @@ static void reset_outputs(const Bufs& b) {
   fill32(b.x, b.sz_x / 4, 1.0f, 0.f, 9);
 }
 
-static const int NVAR = 2;      // candidates beside the 128-tile kernel: 256 kernel schedule 0, schedule 1
-static hipError_t launch_candidate(int var, OperandType op, GemmEpilogue e, const GemmArgs& g) { return launch_vit_gemm256_variant(var, op, e, g, 0); }
-static bool candidate_fits(int, GemmEpilogue e, const GemmArgs& g) { return vit_gemm256_fits(e, g); }
+static const int NVAR = 3;      // candidates beside the 128-tile kernel: 256 kernel schedule 0, schedule 1, the rolling persistent kernel
+static hipError_t launch_candidate(int var, OperandType op, GemmEpilogue e, const GemmArgs& g) {
+  return var == 2 ? launch_vit_gemm_roll(op, e, g, 0) : launch_vit_gemm256_variant(var, op, e, g, 0);
+}
+static bool candidate_fits(int var, GemmEpilogue e, const GemmArgs& g) { return var == 2 ? vit_gemm_roll_fits(e, g) : vit_gemm256_fits(e, g); }
 static int check(int B, int side, int D, bool bf) {
   Bufs b = make(B, side, D, bf);
   const OperandType op = bf ? OP_BF16 : OP_F16;
@@ -112,6 +116,7 @@ static int check(int B, int side, int D, bool bf) {
     const std::vector<uint8_t> ref = snapshot(b);
     size_t worst = 0;
     for (int rep = 0; rep < 2 * NVAR; ++rep) {       // repeated: a race would not reproduce identically
+      if (!candidate_fits(rep % NVAR, c.e, g)) continue;
       reset_outputs(b);
       CK(launch_candidate(rep % NVAR, op, c.e, g)); CK(hipDeviceSynchronize());
       const std::vector<uint8_t> got = snapshot(b);
@@ -136,8 +141,8 @@ static void time_all(int B, int side, int D) {
   CK(hipMemset(b.ls, 0, D * 4));              // x stays bounded over repeated residual launches
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int rounds = 7, it = 10;
-  printf("B=%d (M=%d), D=%d, T=%d      median us (TFLOP/s): old 128-tile kernel | 256 kernel, schedule 0 | schedule 1\n", B, b.M, D, b.T);
-  double tot[1 + NVAR] = {0, 0, 0}, totfl = 0;
+  printf("B=%d (M=%d), D=%d, T=%d      median us (TFLOP/s): old 128-tile kernel | 256 kernel, schedule 0 | schedule 1 | rolling\n", B, b.M, D, b.T);
+  double tot[1 + NVAR] = {0, 0, 0, 0}, totfl = 0;
   for (const Case& c : CASES) {
     GemmArgs g = args_for(b, c);
     std::vector<float> tt[1 + NVAR];
@@ -157,7 +162,7 @@ static void time_all(int B, int side, int D) {
     printf("  %s %6dx%4dx%4d ", c.name, g.M, g.N, g.K);
     const int mult = c.which <= 3 ? 12 : (c.which == 4 ? 1 : 0);   // launches per 12-block forward (11 + 1 qkv with capture ignored)
     for (int which = 0; which < 1 + NVAR; ++which) {
-      if (tt[which].empty()) { printf(" |      -        "); continue; }
+      if (tt[which].empty()) { printf(" |      -        "); if (which == NVAR && !tt[2].empty()) tot[which] += mult * tt[2][tt[2].size() / 2]; continue; }
       std::sort(tt[which].begin(), tt[which].end());
       const double us = tt[which][tt[which].size() / 2];
       printf(" | %7.1f (%5.0f)", us, fl / us / 1e6);
@@ -180,7 +185,7 @@ static void stamps(int B, int side, int D) {
   unsigned long long* dbuf; CK(hipMalloc(&dbuf, maxwg * 4 * 8));
   std::vector<unsigned long long> h(maxwg * 4);
   printf("stamps B=%d: mean shader-clock cycles per workgroup (100 MHz s_memtime ticks x clock ratio not applied: raw s_memtime units)\n", B);
-  for (int var = 0; var < NVAR; ++var)
+  for (int var = 0; var < 2; ++var)
     for (const Case& c : CASES) {
       GemmArgs g = args_for(b, c);
       if (!vit_gemm256_fits(c.e, g)) continue;
@@ -205,8 +210,50 @@ static void stamps(int B, int side, int D) {
   release(b);
 }
 
+// the rolling kernel: per workgroup, cycles of each tile's first two K-tiles (with the previous tile's hooks), its middle
+// K-tiles, its last two (with its own hooks), and the final drain
+static void roll_stamps_report(int B, int side, int D) {
+  Bufs b = make(B, side, D, false);
+  CK(hipMemset(b.ls, 0, D * 4));
+  unsigned long long* dbuf; CK(hipMalloc(&dbuf, 256 * 64 * 8));
+  std::vector<unsigned long long> h(256 * 64);
+  for (const Case& c : CASES) {
+    GemmArgs g = args_for(b, c);
+    if (!vit_gemm_roll_fits(c.e, g)) continue;
+    for (int i = 0; i < 3; ++i) CK(launch_vit_gemm_roll(OP_F16, c.e, g, 0));
+    CK(hipMemset(dbuf, 0, 256 * 64 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(roll_stamps), &dbuf, sizeof(dbuf)));
+    CK(launch_vit_gemm_roll(OP_F16, c.e, g, 0));
+    CK(hipDeviceSynchronize());
+    unsigned long long* nul = nullptr;
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(roll_stamps), &nul, sizeof(nul)));
+    CK(hipMemcpy(h.data(), dbuf, 256 * 64 * 8, hipMemcpyDeviceToHost));
+    const int nkk = g.K / 64;
+    double pro = 0, first2[8] = {0}, mid[8] = {0}, last2a[8] = {0}, last2b[8] = {0}, drain = 0; int cnt[8] = {0}, nwg = 0;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int w = 0; w < 256; ++w) {
+      const unsigned long long* s = &h[64 * w];
+      if (!s[1]) continue;
+      ++nwg; pro += (double)(s[1] - s[0]); t0 = std::min(t0, s[0]);
+      int ti = 0;
+      for (; ti < 8 && s[6 + 5 * ti]; ++ti) {
+        first2[ti] += (double)(s[3 + 5 * ti] - s[2 + 5 * ti]); mid[ti] += (double)(s[4 + 5 * ti] - s[3 + 5 * ti]);
+        last2a[ti] += (double)(s[5 + 5 * ti] - s[4 + 5 * ti]); last2b[ti] += (double)(s[6 + 5 * ti] - s[5 + 5 * ti]); ++cnt[ti];
+      }
+      drain += (double)(s[2 + 5 * ti] - s[1 + 5 * ti]); t1 = std::max(t1, s[2 + 5 * ti]);
+    }
+    printf("rolling %s B=%d: %d workgroups, prologue %.0f, drain %.0f, kernel span %llu cycles\n", c.name, B, nwg, pro / nwg, drain / nwg, t1 - t0);
+    for (int ti = 0; ti < 8 && cnt[ti]; ++ti)
+      printf("   tile %d (%3d WGs): K-tiles 0-1 %7.0f | %d middle K-tiles %7.0f (%5.0f each) | last-but-one %6.0f | last %6.0f\n", ti, cnt[ti],
+             first2[ti] / cnt[ti], nkk - 4, mid[ti] / cnt[ti], mid[ti] / cnt[ti] / (nkk - 4), last2a[ti] / cnt[ti], last2b[ti] / cnt[ti]);
+  }
+  CK(hipFree(dbuf));
+  release(b);
+}
+
 int main(int argc, char** argv) {
   setenv("PIO_GEMM256_MIN_TILES", "0", 1);     // launch_vit_gemm stays the 128-tile kernel here: it is the reference column
+  setenv("PIO_GEMM_ROLL_MIN_TILES", "0", 1);
   const std::string mode = argc > 1 ? argv[1] : "both";
   std::vector<int> Bs;
   for (int i = 2; i < argc; ++i) Bs.push_back(atoi(argv[i]));
@@ -223,6 +270,8 @@ int main(int argc, char** argv) {
   }
   if (mode == "stamps")
     for (int B : Bs) stamps(B, 16, 768);
+  if (mode == "rollstamps")
+    for (int B : Bs) roll_stamps_report(B, 16, 768);
   if (mode == "time" || mode == "both")
     for (int B : Bs) time_all(B, 16, 768);
   return bad ? 1 : 0;
