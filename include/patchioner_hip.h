@@ -71,6 +71,13 @@ typedef struct {
   /* numerics of the ViT MFMA path: 0 = fp16 operands, 1 = bf16 operands (fp32 accumulate either way) */
   int32_t vit_operand_type;
   int32_t device;             /* HIP device ordinal */
+  /* backbone family.  0: DINOv2 (torch.hub, P/src/model.py:342-343: LayerScale, exact-erf GELU, registers, interpolated
+   * position grid).  1: the OpenAI-CLIP ViT the reference loads through timm with QuickGELU for its "DeCap original"
+   * configurations (P/src/model.py:358-392, 786-796; configs/decap_B16*.k.yaml, decap_B32.k.yaml): patch 16 / 32, no
+   * registers, norm_pre after the position add, no LayerScale, x * sigmoid(1.702 x), final norm on every token and the
+   * bias-free head (embed_dim -> vit_out_dim) applied to every token; no qkv hook (has_attention = False, :864-865). */
+  int32_t vit_arch;
+  int32_t vit_out_dim;        /* width of the tokens pio_vit_forward returns: 0 = embed_dim; 512 for the CLIP ViT-B head */
 } pio_config;
 
 const char* pio_last_error(void);

@@ -116,6 +116,57 @@ class DinoV2Oracle:
                 "x_norm_patchtokens": xn[:, R + 1:], "x_prenorm": x}
 
 
+class ClipViTOracle:
+    """The OpenAI-CLIP vision tower as the reference runs it (P/src/model.py:358-392, 786-796):
+    ``timm.create_model('vit_base_patch16_clip_224.openai', act_layer=QuickGELU)`` then
+    ``output = dino.forward_features(imgs); output = dino.head(output)`` on EVERY token.
+
+    timm is a third-party dependency that is absent here (R/requirements.txt lists ``timm`` unpinned); this restates the
+    public ``timm.models.vision_transformer.VisionTransformer`` forward for the CLIP configuration (pre_norm=True,
+    nn.LayerNorm eps 1e-5, class token with a position of its own, no LayerScale, qkv bias, bias-free patch conv,
+    ``fc_norm`` absent) with the reference's QuickGELU (model.py:363-365).  Second opinion, like DinoV2Oracle's:
+    ``transformers.CLIPVisionModelWithProjection`` (tests/golden/clip_vit_hf.npz, tools/oracle/gen_golden.py: gen_clip_hf).
+    State-dict keys are timm's: cls_token, pos_embed, patch_embed.proj.weight, norm_pre.*, blocks.{i}.{norm1, attn.qkv,
+    attn.proj, norm2, mlp.fc1, mlp.fc2}.*, norm.*, head.weight (+ head.bias, zeros in timm's converted checkpoint)."""
+
+    has_attention = False          # model.py:864-865: no qkv hook on this backbone
+    R = 0
+
+    def __init__(self, w: Dict[str, torch.Tensor], num_heads: int, patch_size: int = 16, eps: float = 1e-5):
+        self.w = {k: v.detach().float().cpu() for k, v in w.items()}
+        self.num_heads, self.patch_size, self.eps = num_heads, patch_size, eps
+        self.depth = 1 + max(int(k.split(".")[1]) for k in self.w if k.startswith("blocks."))
+        self.Dv = self.w["cls_token"].shape[-1]
+        self.D = self.w["head.weight"].shape[0]      # width of the tokens handed on (512 for ViT-B)
+        self.last_qkv = None
+
+    def forward_features(self, imgs: torch.Tensor) -> torch.Tensor:
+        w, D, h = self.w, self.Dv, self.num_heads
+        B = imgs.shape[0]
+        x = F.conv2d(imgs.float(), w["patch_embed.proj.weight"], w.get("patch_embed.proj.bias"), stride=self.patch_size)
+        x = x.flatten(2).transpose(1, 2)
+        x = torch.cat([w["cls_token"].reshape(1, 1, D).expand(B, -1, -1), x], dim=1)
+        x = x + w["pos_embed"].reshape(1, -1, D)                 # native grid: timm resamples for other sizes (not restated)
+        x = F.layer_norm(x, (D,), w["norm_pre.weight"], w["norm_pre.bias"], self.eps)
+        T = x.shape[1]
+        for i in range(self.depth):
+            pre = "blocks.%d." % i
+            y = F.layer_norm(x, (D,), w[pre + "norm1.weight"], w[pre + "norm1.bias"], self.eps)
+            q, k, v = F.linear(y, w[pre + "attn.qkv.weight"], w[pre + "attn.qkv.bias"]).reshape(B, T, 3, h, D // h).permute(2, 0, 3, 1, 4)
+            a = ((q * (D // h) ** -0.5) @ k.transpose(-2, -1)).softmax(dim=-1)
+            y = (a @ v).transpose(1, 2).reshape(B, T, D)
+            x = x + F.linear(y, w[pre + "attn.proj.weight"], w[pre + "attn.proj.bias"])
+            y = F.layer_norm(x, (D,), w[pre + "norm2.weight"], w[pre + "norm2.bias"], self.eps)
+            y = F.linear(y, w[pre + "mlp.fc1.weight"], w[pre + "mlp.fc1.bias"])
+            y = y * torch.sigmoid(1.702 * y)                     # QuickGELU, model.py:363-365
+            x = x + F.linear(y, w[pre + "mlp.fc2.weight"], w[pre + "mlp.fc2.bias"])
+        return F.layer_norm(x, (D,), w["norm.weight"], w["norm.bias"], self.eps)
+
+    def __call__(self, imgs: torch.Tensor) -> Dict[str, torch.Tensor]:
+        out = F.linear(self.forward_features(imgs), self.w["head.weight"], self.w.get("head.bias"))   # model.py:790
+        return {"x_norm_clstoken": out[:, 0], "x_norm_regtokens": out[:, 1:1], "x_norm_patchtokens": out[:, 1:]}
+
+
 # --------------------------------------------------------------------------------------------
 # a4 / a5  CLS-row attention read-out and attention-weighted means
 # --------------------------------------------------------------------------------------------
@@ -465,6 +516,13 @@ class DeCapOracle:
 
     fast = False        # tests with hundreds of prefixes set this: the same arithmetic through gpt2_logits_cached
 
+    def logits_after(self, clip_features: torch.Tensor, history: torch.Tensor) -> torch.Tensor:
+        """Logits [V] of the position that follows ``history`` (ids already decoded, possibly none) for ONE prefix."""
+        emb = self.clip_project(clip_features.reshape(1, -1)).view(1, 1, -1)
+        if history.numel():
+            emb = torch.cat((emb, self.w["decoder.transformer.wte.weight"][history.long()].unsqueeze(0)), dim=1)
+        return self.gpt2_logits(emb)[0, -1]
+
     def decode_ids(self, clip_features: torch.Tensor, entry_length: int = 30, cached: Optional[bool] = None):
         """P/src/decap/decap.py:116-155: 30 full forwards over the growing sequence; returns
         (ids [N,30] int64, per-token log-probs [N,30], top-2 logit margin [N,30]).
@@ -544,6 +602,8 @@ class PatchionerOracle:
         self.last_ids = ids
         if self.call_log is not None:
             self.call_log.append(ids.clone())
+        if getattr(self, "prefix_log", None) is not None:      # tests: the fp32 path's decoder inputs, for the derived parity bound
+            self.prefix_log.append(x.detach().clone())
         caps = ids_to_captions(ids.tolist(), self.decode_fn)
         if compute_scores:
             return caps, torch.exp(lps.sum(-1)).tolist()
@@ -559,9 +619,14 @@ class PatchionerOracle:
         bs = imgs.shape[0]
         d = self.vit(imgs)
         patches = d["x_norm_patchtokens"]
-        self_attn, maps = process_self_attention(self.vit.last_qkv, bs, self.num_tokens, self.num_attn_heads,
-                                                 self.embed_dim, self.scale, self.num_global_tokens)
-        avg_tok, disentangled = attention_weighted_means(self_attn, maps, patches)
+        if getattr(self.vit, "has_attention", True):
+            self_attn, maps = process_self_attention(self.vit.last_qkv, bs, self.num_tokens, self.num_attn_heads,
+                                                     self.embed_dim, self.scale, self.num_global_tokens)
+            avg_tok, disentangled = attention_weighted_means(self_attn, maps, patches)
+        else:       # model.py:864-872: nothing defines these for a backbone without the qkv hook; their readers fail
+            self_attn = maps = avg_tok = disentangled = None
+            if clean_from != "cls":
+                clean_from = "cls"                       # model.py:886-890: fallback to the cls token
         if cleaning_type is not None:
             # P/src/model.py:879-922.  project() normalises its argument IN PLACE: with clean_after_projection the
             # patch tokens and the clean-from token of the backbone output are left L2-normalised.

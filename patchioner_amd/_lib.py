@@ -34,6 +34,7 @@ class PioConfig(ctypes.Structure):
         ("dec_positions", c_int32), ("prefix_size", c_int32), ("dec_ln_eps", c_float),
         ("max_batch", c_int32), ("max_prefixes", c_int32), ("max_steps", c_int32),
         ("vit_operand_type", c_int32), ("device", c_int32),
+        ("vit_arch", c_int32), ("vit_out_dim", c_int32),
     ]
 
 

@@ -87,6 +87,11 @@ struct pio_context {
   // ViT weights
   void* pe_w = nullptr; float* pe_b = nullptr; float* pos = nullptr; float* cls = nullptr; float* reg = nullptr;
   float *norm_w = nullptr, *norm_b = nullptr;
+  float *npre_w = nullptr, *npre_b = nullptr;   // CLIP: norm_pre
+  float* vhead_w = nullptr;                      // CLIP: head.weight [vit_out_dim][D], fp32
+  float* ones = nullptr;                         // CLIP: "LayerScale" of ones (x += 1 * branch is exact)
+  float* tok_tmp = nullptr;                      // CLIP: final-norm tokens [max_batch * T][D] before the head
+  int Dout = 0;                                  // width of the returned tokens
   std::vector<VitLayerDev> vl;
   // ViT workspaces
   float* x = nullptr; void* xn = nullptr; void* ao = nullptr; void* hbuf = nullptr; void* ape = nullptr;
@@ -219,10 +224,16 @@ int finalize_vit(pio_context* c) {
   const int D = c->D, depth = c->cfg.depth, p = c->cfg.patch_size, R = c->cfg.num_registers;
   const HostTensor* t;
   int rc;
+  const bool clip = c->cfg.vit_arch == 1;
   if ((rc = need(c, "patch_embed.proj.weight", {D, 3, p, p}, &t))) return rc;
   if ((rc = upload_op(c, t->data.data(), D, c->Kpe, c->Kpad, &c->pe_w))) return rc;
-  if ((rc = need(c, "patch_embed.proj.bias", {D}, &t))) return rc;
-  if ((rc = upload_f32(c, t->data.data(), D, &c->pe_b))) return rc;
+  if (clip && !find(c, "patch_embed.proj.bias")) {          // CLIP's conv1 has no bias (timm: patch_embed.proj.bias absent)
+    const std::vector<float> zeros(D, 0.f);
+    if ((rc = upload_f32(c, zeros.data(), D, &c->pe_b))) return rc;
+  } else {
+    if ((rc = need(c, "patch_embed.proj.bias", {D}, &t))) return rc;
+    if ((rc = upload_f32(c, t->data.data(), D, &c->pe_b))) return rc;
+  }
   if ((rc = need(c, "cls_token", {D}, &t))) return rc;
   if ((rc = upload_f32(c, t->data.data(), D, &c->cls))) return rc;
   if (R > 0) {
@@ -235,7 +246,8 @@ int finalize_vit(pio_context* c) {
     std::vector<float> pos((size_t)(1 + c->n2) * D);
     // hub variants: *_reg models interpolate with antialias and offset 0, the models without registers without
     // antialias and with the historical 0.1 offset (dinov2/hub/backbones.py)
-    if (R > 0) interpolate_pos_embed(t->data.data(), g, D, c->n, pos.data());
+    if (clip) pos.assign(t->data.begin(), t->data.end());            // native grid (pio_create): the learned table as it is
+    else if (R > 0) interpolate_pos_embed(t->data.data(), g, D, c->n, pos.data());
     else interpolate_pos_embed_plain(t->data.data(), g, D, c->n, 0.1, pos.data());
     if ((rc = upload_f32(c, pos.data(), pos.size(), &c->pos))) return rc;
   }
@@ -243,6 +255,21 @@ int finalize_vit(pio_context* c) {
   if ((rc = upload_f32(c, t->data.data(), D, &c->norm_w))) return rc;
   if ((rc = need(c, "norm.bias", {D}, &t))) return rc;
   if ((rc = upload_f32(c, t->data.data(), D, &c->norm_b))) return rc;
+  if (clip) {
+    if ((rc = need(c, "norm_pre.weight", {D}, &t))) return rc;
+    if ((rc = upload_f32(c, t->data.data(), D, &c->npre_w))) return rc;
+    if ((rc = need(c, "norm_pre.bias", {D}, &t))) return rc;
+    if ((rc = upload_f32(c, t->data.data(), D, &c->npre_b))) return rc;
+    const std::vector<float> ones(D, 1.f);
+    if ((rc = upload_f32(c, ones.data(), D, &c->ones))) return rc;
+    if (c->Dout != D || find(c, "head.weight")) {
+      if ((rc = need(c, "head.weight", {c->Dout, D}, &t))) return rc;
+      if ((rc = upload_f32(c, t->data.data(), t->data.size(), &c->vhead_w))) return rc;
+      if ((rc = c->dmalloc(&c->tok_tmp, (size_t)c->cfg.max_batch * c->T * D, true))) return rc;
+    }
+  } else if (c->Dout != D) {
+    return fail(PIO_ERR_INVALID_ARG, "vit_out_dim != embed_dim needs vit_arch 1");
+  }
   c->vl.resize(depth);
   for (int l = 0; l < depth; ++l) {
     VitLayerDev& L = c->vl[l];
@@ -253,6 +280,7 @@ int finalize_vit(pio_context* c) {
               {"norm2.bias", D, &L.n2b}, {"mlp.fc1.bias", 4 * D, &L.fc1b}, {"mlp.fc2.bias", D, &L.fc2b},
               {"ls2.gamma", D, &L.ls2}};
     for (auto& f : fs) {
+      if (clip && (f.dst == &L.ls1 || f.dst == &L.ls2)) { *f.dst = c->ones; continue; }     // no LayerScale
       if ((rc = need(c, pre + f.key, {f.n}, &t))) return rc;
       if ((rc = upload_f32(c, t->data.data(), f.n, f.dst))) return rc;
     }
@@ -487,7 +515,7 @@ bool is_ignorable_key(const std::string& k) {
 
 bool is_known_key(const std::string& k) {
   static const char* exact[] = {"cls_token", "pos_embed", "register_tokens", "patch_embed.proj.weight",
-                                "patch_embed.proj.bias", "norm.weight", "norm.bias", "talk2dino.A_pinv",
+                                "patch_embed.proj.bias", "norm.weight", "norm.bias", "norm_pre.weight", "norm_pre.bias", "head.weight", "talk2dino.A_pinv",
                                 "talk2dino.b"};
   for (auto e : exact) if (k == e) return true;
   return k.rfind("blocks.", 0) == 0 || k.rfind("decoder.transformer.", 0) == 0 || k.rfind("clip_project.model.0.", 0) == 0 ||
@@ -594,6 +622,11 @@ int pio_create(const pio_config* cfg, pio_handle* out) {
     return fail(PIO_ERR_INVALID_ARG, "pio_create: capacities out of range (prefixes <= 128, decoder positions <= 256)");
   if (cfg->readout_heads != 16 && cfg->readout_heads * 64 != cfg->embed_dim)
     return fail(PIO_ERR_INVALID_ARG, "pio_create: readout_heads must be 16, or embed_dim / 64 (ViT-S: 6)");
+  if (cfg->vit_arch != 0 && cfg->vit_arch != 1) return fail(PIO_ERR_INVALID_ARG, "pio_create: vit_arch must be 0 (DINOv2) or 1 (OpenAI-CLIP ViT)");
+  if (cfg->vit_arch == 1 && (cfg->num_registers != 0 || cfg->pretrain_grid * cfg->patch_size != cfg->crop_dim))
+    return fail(PIO_ERR_INVALID_ARG, "pio_create: the CLIP ViT has no registers and runs at its native grid (crop_dim = pretrain_grid * patch_size)");
+  if (cfg->vit_out_dim < 0 || (cfg->vit_out_dim > 0 && cfg->vit_out_dim % 32 != 0) || (cfg->vit_arch == 0 && cfg->vit_out_dim != 0 && cfg->vit_out_dim != cfg->embed_dim))
+    return fail(PIO_ERR_INVALID_ARG, "pio_create: vit_out_dim must be 0, or a multiple of 32 with vit_arch 1");
   int ndev = 0;
   HIP_OK(hipGetDeviceCount(&ndev));
   if (cfg->device < 0 || cfg->device >= ndev) return fail(PIO_ERR_INVALID_ARG, "pio_create: no such HIP device");
@@ -611,6 +644,7 @@ int pio_create(const pio_config* cfg, pio_handle* out) {
   c->Kpe = 3 * cfg->patch_size * cfg->patch_size;
   c->Kpad = round_up(c->Kpe, 64);
   c->op = cfg->vit_operand_type == 1 ? OP_BF16 : OP_F16;
+  c->Dout = cfg->vit_out_dim > 0 ? cfg->vit_out_dim : cfg->embed_dim;
   const char* ng = getenv("PIO_NO_GRAPH");
   c->use_graph = !(ng && ng[0] == '1');
   hipError_t e = hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking);
@@ -627,7 +661,7 @@ int pio_clone_decoder(pio_handle src, pio_handle* out) {
   pio_context* c = new pio_context();
   c->cfg = src->cfg;
   c->n = src->n; c->n2 = src->n2; c->T = src->T; c->Tp = src->Tp; c->Tk = src->Tk; c->G = src->G; c->D = src->D;
-  c->Kpe = src->Kpe; c->Kpad = src->Kpad; c->H = src->H; c->op = src->op;
+  c->Kpe = src->Kpe; c->Kpad = src->Kpad; c->H = src->H; c->op = src->op; c->Dout = src->Dout;
   c->use_graph = src->use_graph;
   // borrowed, read-only: the decoder's weights (freed by the owner only)
   c->clip_w = src->clip_w; c->clip_b = src->clip_b; c->wte = src->wte; c->wpe = src->wpe;
@@ -812,6 +846,7 @@ static int run_vit_block(pio_handle c, const VitLayerDev& L, int B, const GemmAr
   {
     GemmArgs a = g;
     a.A = c->xn; a.lda = D; a.W = L.fc1w; a.bias = L.fc1b; a.out16 = c->hbuf; a.M = M; a.N = 4 * D; a.K = D;
+    a.act = c->cfg.vit_arch == 1 ? 1 : 0;
     PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * 4.0 * D * D, 0, s, launch_vit_gemm(c->op, EPI_GELU, a, s));
   }
   {
@@ -824,6 +859,7 @@ static int run_vit_block(pio_handle c, const VitLayerDev& L, int B, const GemmAr
 
 int pio_vit_forward(pio_handle c, const float* imgs, int32_t B, float* tokens, float* qkv_last, pio_stream stream) {
   if (!c || !imgs || !tokens) return fail(PIO_ERR_INVALID_ARG, "pio_vit_forward: null argument");
+  if (c->cfg.vit_arch == 1 && qkv_last) return fail(PIO_ERR_INVALID_ARG, "pio_vit_forward: the CLIP ViT has no qkv capture (no hook in the reference, P/src/model.py:586-590 is DINOv2 only)");
   if (!c->has_vit) return fail(PIO_ERR_NOT_READY, "pio_vit_forward: backbone weights not loaded");
   if (B < 1 || B > c->cfg.max_batch) return fail(PIO_ERR_CAPACITY, "pio_vit_forward: batch above max_batch");
   HIP_OK(hipSetDevice(c->cfg.device));
@@ -840,6 +876,8 @@ int pio_vit_forward(pio_handle c, const float* imgs, int32_t B, float* tokens, f
     a.A = c->ape; a.lda = c->Kpad; a.W = c->pe_w; a.bias = c->pe_b; a.M = B * c->n2; a.N = D; a.K = c->Kpad;
     PROF(c, PIO_PROF_VIT_GEMM, 2.0 * B * c->n2 * (double)D * c->Kpe, 0, s, launch_vit_gemm(c->op, EPI_PATCH_EMBED, a, s));
   }
+  if (c->cfg.vit_arch == 1)     // CLIP: norm_pre on the position-added tokens, in place (fp32; every row is read whole before it is written)
+    HIP_OK(launch_layernorm(c->op, c->x, c->npre_w, c->npre_b, c->cfg.vit_ln_eps, M, D, nullptr, c->x, c->Tp, c->Tp, s));
   VitAttnArgs at;
   at.q = c->q; at.k = c->k; at.vT = c->vT; at.out = c->ao; at.B = B; at.H = c->H; at.T = c->T; at.Tp = c->Tp;
   at.Tk = c->Tk; at.D = D; at.scale = 0.125f;  // 64^-0.5
@@ -847,6 +885,12 @@ int pio_vit_forward(pio_handle c, const float* imgs, int32_t B, float* tokens, f
   for (int l = 0; l < depth; ++l) {
     const int rc = run_vit_block(c, c->vl[l], B, g, at, (l == depth - 1) ? qkv_last : nullptr, s);
     if (rc != PIO_OK) return rc;
+  }
+  if (c->vhead_w) {
+    // CLIP: forward_features' final norm on every token, then the bias-free head on every token (model.py:788-790): exact fp32
+    HIP_OK(launch_layernorm(c->op, c->x, c->norm_w, c->norm_b, c->cfg.vit_ln_eps, M, D, nullptr, c->tok_tmp, c->T, c->Tp, s));
+    HIP_OK(launch_sgemm_tn(c->tok_tmp, D, c->vhead_w, D, nullptr, 1.f, tokens, c->Dout, B * c->T, c->Dout, D, 0, 0, s));
+    return PIO_OK;
   }
   HIP_OK(launch_layernorm(c->op, c->x, c->norm_w, c->norm_b, c->cfg.vit_ln_eps, M, D, nullptr, tokens, c->T, c->Tp, s));
   return PIO_OK;
@@ -856,6 +900,7 @@ int pio_bbox_double_dino(pio_handle c, const float* tokens, const int32_t* slice
                          int32_t return_type, float* out, pio_stream stream) {
   if (!c || !tokens || !slices || !out) return fail(PIO_ERR_INVALID_ARG, "pio_bbox_double_dino: null argument");
   if (!c->has_vit) return fail(PIO_ERR_NOT_READY, "pio_bbox_double_dino: backbone weights not loaded");
+  if (c->cfg.vit_arch == 1) return fail(PIO_ERR_INVALID_ARG, "pio_bbox_double_dino: DINOv2 backbones only (P/src/bbox_utils.py:300-403 re-runs a DINOv2 block)");
   if (B < 1 || NB < 1) return fail(PIO_ERR_INVALID_ARG, "pio_bbox_double_dino: empty batch");
   if (return_type < 0 || return_type > 1) return fail(PIO_ERR_INVALID_ARG, "pio_bbox_double_dino: return_type 0 (cls) or 1 (avg)");
   if (return_type == 0 && !use_cls) return fail(PIO_ERR_INVALID_ARG, "pio_bbox_double_dino: return_type cls needs use_cls");
@@ -889,6 +934,7 @@ int pio_cls_attention(pio_handle c, const float* qkv_last, const float* tokens, 
                       float* head_maps, float* avg_token, float* disentangled, pio_stream stream) {
   if (!c || !qkv_last || !self_attn) return fail(PIO_ERR_INVALID_ARG, "pio_cls_attention: null argument");
   if (!c->has_vit) return fail(PIO_ERR_NOT_READY, "pio_cls_attention: backbone not loaded");
+  if (c->cfg.vit_arch == 1) return fail(PIO_ERR_INVALID_ARG, "pio_cls_attention: the CLIP ViT exposes no qkv hook (has_attention = False, P/src/model.py:864-865)");
   if (B < 1 || B > c->cfg.max_batch) return fail(PIO_ERR_CAPACITY, "pio_cls_attention: batch above max_batch");
   if ((avg_token || disentangled) && !tokens) return fail(PIO_ERR_INVALID_ARG, "pio_cls_attention: tokens required");
   HIP_OK(hipSetDevice(c->cfg.device));
@@ -935,7 +981,7 @@ int pio_region_reduce(pio_handle c, const float* tokens, int32_t B, const float*
   if (R < 1 || B < 1) return fail(PIO_ERR_INVALID_ARG, "pio_region_reduce: empty input");
   if (!img_index && R > B) return fail(PIO_ERR_INVALID_ARG, "pio_region_reduce: img_index required when R > B");
   HIP_OK(hipSetDevice(c->cfg.device));
-  HIP_OK(launch_region_reduce(tokens, c->T, c->G, c->D, c->n2, weights, img_index, R, scale, out, (hipStream_t)stream));
+  HIP_OK(launch_region_reduce(tokens, c->T, c->G, c->Dout, c->n2, weights, img_index, R, scale, out, (hipStream_t)stream));
   return PIO_OK;
 }
 
@@ -1229,7 +1275,11 @@ int pio_preprocess(pio_handle c, const void* pixels, const int64_t* offsets, con
   HIP_OK(hipSetDevice(c->cfg.device));
   const int S = mode == 0 ? crop_dim : resize_dim;
   if (!c->prep_lut) {   // ((v / 255) - mean) / std in IEEE fp32, the operations of ToTensor + Normalize
-    static const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    // ImageNet statistics for DINOv2 (P/src/model.py:351), OpenAI-CLIP's for the CLIP ViT (:381-382)
+    static const float mean_in[3] = {0.485f, 0.456f, 0.406f}, std_in[3] = {0.229f, 0.224f, 0.225f};
+    static const float mean_cl[3] = {0.48145466f, 0.4578275f, 0.40821073f}, std_cl[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+    const float* mean = c->cfg.vit_arch == 1 ? mean_cl : mean_in;
+    const float* stdv = c->cfg.vit_arch == 1 ? std_cl : std_in;
     std::vector<float> lut(768);
     for (int ch = 0; ch < 3; ++ch)
       for (int v = 0; v < 256; ++v) {

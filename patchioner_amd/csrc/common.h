@@ -111,6 +111,14 @@ __device__ __forceinline__ pio_f32x2 gelu_erf2(pio_f32x2 v) {
   return r;
 }
 
+// QuickGELU of the OpenAI-CLIP towers, x * sigmoid(1.702 x) (P/src/model.py:363-365), as x / (1 + 2^(-1.702 log2(e) x)):
+// one v_exp_f32, one v_rcp_f32 (1 ulp), three plain VALU.  One definition for every GEMM kernel: an output element does not
+// depend on which of them produced it.  (x -> -inf: 2^(+inf) = inf, rcp = 0, x * 0 = -0 ... only at |x| beyond fp16 anyway.)
+__device__ __forceinline__ float quick_gelu(float v) {
+  const float e = __builtin_amdgcn_exp2f(v * -2.4554669595930157f);
+  return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

@@ -31,6 +31,7 @@ struct GemmArgs {
   void* q; void* k; void* vT;   // QKV outputs
   float* qkv_last;     // optional fp32 capture [B][T][3D]
   int T, Tp, Tk, G, n2, D, H;  // tokens / padded rows per image / padded key count / global tokens / patches
+  int act;             // EPI_GELU: 0 = exact-erf GELU (DINOv2), 1 = QuickGELU x * sigmoid(1.702 x) (OpenAI-CLIP towers)
 };
 
 hipError_t launch_vit_gemm(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s);

@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? PIO_GEMM_WIDE_OCC
         xo.x += l4.x * v.x; xo.y += l4.y * v.y; xo.z += l4.z * v.z; xo.w += l4.w * v.w;
         *px = xo;
       } else if constexpr (EPI == EPI_GELU) {
-        store_half4<T>((T*)g.out16 + (size_t)m * g.N + n, gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+        if (g.act == 1) store_half4<T>((T*)g.out16 + (size_t)m * g.N + n, quick_gelu(v.x), quick_gelu(v.y), quick_gelu(v.z), quick_gelu(v.w));
+        else store_half4<T>((T*)g.out16 + (size_t)m * g.N + n, gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
       } else {  // EPI_QKV, q or k block
         const int which = n0 >= g.D ? 1 : 0;
         const int hd = n - which * g.D, head = hd >> 6, d = hd & 63;

@@ -386,8 +386,12 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm256(const GemmArgs g) {
             float v0 = acc[i][j][rt][4 * a + 0] + b4.x, v1 = acc[i][j][rt][4 * a + 1] + b4.y;
             float v2 = acc[i][j][rt][4 * a + 2] + b4.z, v3 = acc[i][j][rt][4 * a + 3] + b4.w;
             if constexpr (EPI == EPI_GELU) {
-              const pio_f32x2 g01 = gelu_erf2((pio_f32x2){v0, v1}), g23 = gelu_erf2((pio_f32x2){v2, v3});
-              v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
+              if (g.act == 1) {
+                v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3);
+              } else {
+                const pio_f32x2 g01 = gelu_erf2((pio_f32x2){v0, v1}), g23 = gelu_erf2((pio_f32x2){v2, v3});
+                v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
+              }
             }
             half4_t o;
             o[0] = (T)v0; o[1] = (T)v1; o[2] = (T)v2; o[3] = (T)v3;

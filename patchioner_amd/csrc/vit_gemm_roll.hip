@@ -245,7 +245,8 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
       _Pragma("unroll") for (int rt = 0; rt < 2; ++rt) _Pragma("unroll") for (int a = 0; a < 4; ++a) {                      \
         float v0 = acc[q][rt][4 * a], v1 = acc[q][rt][4 * a + 1], v2 = acc[q][rt][4 * a + 2], v3 = acc[q][rt][4 * a + 3];   \
         if constexpr (EPI == EPI_GELU) {                                                                                    \
-          v0 = gelu_erf_plain(v0); v1 = gelu_erf_plain(v1); v2 = gelu_erf_plain(v2); v3 = gelu_erf_plain(v3);               \
+          if (g.act == 1) { v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3); }           \
+          else { v0 = gelu_erf_plain(v0); v1 = gelu_erf_plain(v1); v2 = gelu_erf_plain(v2); v3 = gelu_erf_plain(v3); }      \
         }                                                                                                                   \
         half4_t o;                                                                                                          \
         o[0] = (T)v0; o[1] = (T)v1; o[2] = (T)v2; o[3] = (T)v3;                                                             \

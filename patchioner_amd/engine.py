@@ -26,23 +26,27 @@ class Engine:
                  patch_size: int = 14, pretrain_grid: int = 37, prefix_size: int = 768, dec_layers: int = 4,
                  dec_heads: int = 4, dec_embd: int = 768, dec_vocab: int = 50257, dec_positions: int = 1024,
                  max_batch: int = 16, max_prefixes: int = 64, max_steps: int = 30, vit_dtype: str = "fp16",
-                 device_index: int = 0, readout_heads: int = 16, readout_scale: float = 0.125):
+                 device_index: int = 0, readout_heads: int = 16, readout_scale: float = 0.125, vit_arch: str = "dinov2",
+                 vit_out_dim: int = 0, vit_ln_eps: float = 1e-6):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise PioError(-101, "no HIP device visible: the captioning path has no CPU fallback")
         self.device = torch.device("cuda", device_index)
         cfg = PioConfig(
             embed_dim=embed_dim, depth=depth, num_heads=num_heads, patch_size=patch_size,
-            num_registers=num_registers, pretrain_grid=pretrain_grid, crop_dim=crop_dim, vit_ln_eps=1e-6,
+            num_registers=num_registers, pretrain_grid=pretrain_grid, crop_dim=crop_dim, vit_ln_eps=vit_ln_eps,
             readout_heads=readout_heads, readout_scale=readout_scale, dec_layers=dec_layers, dec_heads=dec_heads,
             dec_embd=dec_embd, dec_vocab=dec_vocab, dec_positions=dec_positions, prefix_size=prefix_size,
             dec_ln_eps=1e-5, max_batch=max_batch, max_prefixes=max_prefixes, max_steps=max_steps,
-            vit_operand_type={"fp16": 0, "bf16": 1}[vit_dtype], device=device_index)
+            vit_operand_type={"fp16": 0, "bf16": 1}[vit_dtype], device=device_index,
+            vit_arch={"dinov2": 0, "clip": 1}[vit_arch], vit_out_dim=vit_out_dim)
         self.cfg = cfg
         h = ctypes.c_void_p()
         check(self.lib.pio_create(ctypes.byref(cfg), ctypes.byref(h)))
         self.h = h
-        self.D, self.G = embed_dim, 1 + num_registers
+        # D = width of the tokens the backbone returns (the CLIP ViT's head maps embed_dim -> vit_out_dim); Dv = its own width
+        self.D, self.G, self.Dv = (vit_out_dim or embed_dim), 1 + num_registers, embed_dim
+        self.vit_arch = vit_arch
         self.n = self.lib.pio_grid_side(h)
         self.T = self.lib.pio_num_tokens(h)
         self.n2 = self.n * self.n
@@ -137,7 +141,9 @@ class Engine:
             # the reference's reshape in process_self_attention fails for any other size
             raise ValueError("images must be [B,3,%d,%d], got %s" % (crop, crop, tuple(imgs.shape)))
         tokens = torch.empty(B, self.T, self.D, device=self.device, dtype=torch.float32)
-        qkv = torch.empty(B, self.T, 3 * self.D, device=self.device, dtype=torch.float32) if want_qkv else None
+        if want_qkv and self.vit_arch != "dinov2":
+            raise PioError(_lib.PIO_ERR_INVALID_ARG, "the CLIP ViT exposes no qkv hook (P/src/model.py:864-865)")
+        qkv = torch.empty(B, self.T, 3 * self.Dv, device=self.device, dtype=torch.float32) if want_qkv else None
         for s in range(0, B, self.max_batch):
             e = min(B, s + self.max_batch)
             check(self.lib.pio_vit_forward(self.h, ptr(imgs[s:e]), e - s, ptr(tokens[s:e]),

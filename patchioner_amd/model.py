@@ -96,8 +96,15 @@ class Patchioner(nn.Module):
                 raise NotImplementedError("%s: backbone/head outside the MI355X hot-path scope (DINOv2 + DeCap/CapDec)" % k)
         if use_open_clip or online_texts is not None:
             raise NotImplementedError("use_open_clip / online_texts need the CLIP text tower: outside the hot-path scope")
-        if dino_model is None or 'dinov2' not in dino_model or 'dinotxt' in dino_model:
-            raise ValueError("Unsupported backbone %r: this build implements the DINOv2 ViT-S/B/L-14 family" % (dino_model,))
+        # P/src/model.py:339-392: 'dinov2' names load from torch.hub, 'openai' names are the timm OpenAI-CLIP towers of the
+        # "DeCap original" configurations (configs/decap_B16*.k.yaml, decap_B32.k.yaml)
+        is_clip = dino_model is not None and 'openai' in dino_model and 'dinov2' not in dino_model
+        if dino_model is None or 'dinotxt' in dino_model or not ('dinov2' in dino_model or is_clip):
+            raise ValueError("Unsupported backbone %r: this build implements the DINOv2 ViT-S/B/L-14 family and the timm "
+                             "OpenAI-CLIP ViTs (vit_base_patch16/32_clip_224.openai)" % (dino_model,))
+        if is_clip and (resize_dim != 224 or crop_dim != 224):
+            # the reference hands img_size=resize_dim to timm, which resamples the position table for any other size
+            raise NotImplementedError("the CLIP ViT runs at its native 224 x 224 (timm would resample its position table)")
         if viecap_config is not None and viecap_config.get('meacap', False):
             raise NotImplementedError("MeaCap head (retrieved-caption scene graphs, flan-T5): outside the hot-path scope")
         if decoder_weights is None and synthetic_seed is None and not calculate_argmax_text and viecap_config is None:
@@ -127,26 +134,36 @@ class Patchioner(nn.Module):
         self.crop_dim = crop_dim
         self.model_name = dino_model
         self.num_global_tokens = 1 if "reg" not in dino_model else 5
-        patch_size = 14
+        if is_clip:
+            # timm VisionTransformer with pre_norm, nn.LayerNorm (eps 1e-5), QuickGELU (model.py:363-371); the reference hands
+            # img_size=resize_dim to timm, which resamples the position table for any other size: native size only here
+            self.embed_dim, depth, heads, patch_size, self.token_dim = W.clip_arch(dino_model)
+        else:
+            patch_size = 14
+            self.embed_dim, depth, heads = W.dino_arch(dino_model)
+            self.token_dim = self.embed_dim
         if crop_dim % patch_size != 0:
-            raise ValueError("crop_dim must be a multiple of 14 (the reference's reshape fails otherwise)")
+            raise ValueError("crop_dim must be a multiple of %d (the reference's reshape fails otherwise)" % patch_size)
         self.num_patch_tokens = crop_dim // patch_size * crop_dim // patch_size
         self.num_tokens = self.num_global_tokens + self.num_patch_tokens
-        self.embed_dim, depth, heads = W.dino_arch(dino_model)
         self.num_attn_heads = 16 if 'vits' not in dino_model else 6
         self.scale = 0.125
         self.patch_size = patch_size
-        self.backbone_type = 'DINO'
-        self.image_transforms, self.image_transforms_no_crop = make_transforms(resize_dim, crop_dim)
+        self.backbone_type = 'CLIP' if is_clip else 'DINO'            # model.py:650-651, :786
+        if is_clip:
+            from .preprocess import CLIP_MEAN, CLIP_STD
+            self.image_transforms, self.image_transforms_no_crop = make_transforms(resize_dim, crop_dim, CLIP_MEAN, CLIP_STD)
+        else:
+            self.image_transforms, self.image_transforms_no_crop = make_transforms(resize_dim, crop_dim)
 
         vit_sd = _load_state_dict(dino_weights)
         if vit_sd is None:
             if synthetic_seed is None:
-                raise FileNotFoundError("dino_weights is required: torch.hub.load('facebookresearch/dinov2', ...) "
-                                        "needs network, which this target does not have")
-            vit_sd = W.synth_dinov2(synthetic_seed + 1, dino_model)
+                raise FileNotFoundError("dino_weights is required: torch.hub.load('facebookresearch/dinov2', ...) / "
+                                        "timm.create_model(..., pretrained=True) need network, which this target does not have")
+            vit_sd = W.synth_clip_vit(synthetic_seed + 1, dino_model) if is_clip else W.synth_dinov2(synthetic_seed + 1, dino_model)
         depth = 1 + max(int(k.split(".")[1]) for k in vit_sd if k.startswith("blocks."))
-        if attention_type != 'qkv':
+        if attention_type != 'qkv' and not is_clip:
             # the reference re-orders the last block's fused q|k|v rows (P/src/model.py:569-582)
             vit_sd = dict(vit_sd)
             D = self.embed_dim
@@ -189,7 +206,9 @@ class Patchioner(nn.Module):
                              num_registers=self.num_global_tokens - 1, crop_dim=crop_dim, patch_size=patch_size,
                              pretrain_grid=int(math.isqrt(vit_sd["pos_embed"].shape[1] - 1)), prefix_size=prefix_size,
                              max_batch=max_batch, max_prefixes=max_prefixes, vit_dtype=vit_dtype,
-                             device_index=self._device.index, readout_heads=self.num_attn_heads, readout_scale=self.scale, **dec_kw)
+                             device_index=self._device.index, readout_heads=self.num_attn_heads, readout_scale=self.scale,
+                             vit_arch="clip" if is_clip else "dinov2", vit_out_dim=self.token_dim if is_clip else 0,
+                             vit_ln_eps=1e-5 if is_clip else 1e-6, **dec_kw)
         self.engine.load_state_dict(vit_sd)
         if dec_sd is not None:                         # calculate_argmax_text without decoder weights: no decoder (model.py:165)
             self.engine.load_state_dict(dec_sd)        # strict=False like the reference (decap.py:214)
@@ -208,14 +227,14 @@ class Patchioner(nn.Module):
                 if self.text_dataset is None:
                     self.text_dataset = texts
             elif synthetic_seed is not None:
-                bank = W.synth_bank(synthetic_seed + 3, support_memory_size, self.embed_dim)
+                bank = W.synth_bank(synthetic_seed + 3, support_memory_size, self.token_dim)
             else:
                 raise FileNotFoundError("support_memory_size > 0 needs `memory_bank` (path or tensor): building the "
                                         "bank (CLIP text tower + datasets) is offline work outside this scope")
-            if 'dinov2' not in dino_model:      # normalize_memory_embs (P/src/model.py:174); never true here
+            if 'dinov2' not in dino_model:      # normalize_memory_embs (P/src/model.py:174; im2txtprojection.py:348-349): the CLIP ViTs
                 bank = bank / bank.norm(dim=-1, keepdim=True)
-            if bank.dim() != 2 or bank.shape[1] != self.embed_dim:
-                raise ValueError("memory bank is %s, the %s backbone needs [M, %d]" % (tuple(bank.shape), dino_model, self.embed_dim))
+            if bank.dim() != 2 or bank.shape[1] != self.token_dim:
+                raise ValueError("memory bank is %s, the %s backbone needs [M, %d]" % (tuple(bank.shape), dino_model, self.token_dim))
             self.engine.set_memory_bank(bank)
             self.im_proj = self.engine
         else:
@@ -350,12 +369,27 @@ class Patchioner(nn.Module):
         eng = self.engine
         outs = {}
         bs = imgs.shape[0]
-        tokens, qkv = eng.vit_forward(imgs, want_qkv=True)
+        # has_attention (model.py:864-865): only DINO backbones install the qkv hook.  Without it the reference never defines
+        # self_attn / avg_self_attn_token / disentangled_self_attn and every option that reads them fails with
+        # UnboundLocalError; clean_from == "avg_self_attn" falls back to the cls token (:886-890).
+        has_attention = 'DINO' in self.backbone_type
+        if double_DINO_for_bboxes and not has_attention:
+            raise AttributeError("double_DINO_for_bboxes re-runs a DINOv2 block (bbox_utils.py:300-403): not a %s backbone" % self.backbone_type)
+        tokens, qkv = eng.vit_forward(imgs, want_qkv=has_attention)
         G = self.num_global_tokens
-        embed_dim = self.embed_dim
-        clean_avg = cleaning_type is not None and clean_from == "avg_self_attn"
-        self_attn, _, avg_self_attn_token, disentangled_self_attn = eng.cls_attention(
-            qkv, tokens, want_maps=False, want_avg=get_avg_self_attn_capt or clean_avg, want_disentangled=get_attn_heads_capt)
+        embed_dim = tokens.shape[-1]                 # model.py:924: the width of x_norm_patchtokens (512 behind the CLIP head)
+        clean_avg = cleaning_type is not None and clean_from == "avg_self_attn" and has_attention
+        if has_attention:
+            self_attn, _, avg_self_attn_token, disentangled_self_attn = eng.cls_attention(
+                qkv, tokens, want_maps=False, want_avg=get_avg_self_attn_capt or clean_avg, want_disentangled=get_attn_heads_capt)
+        else:
+            self_attn = avg_self_attn_token = disentangled_self_attn = None
+            for flag, name in ((get_avg_self_attn_capt, "avg_self_attn_token"), (get_attn_heads_capt, "disentangled_self_attn"),
+                               (use_attn_map_for_bboxes and bboxes is not None, "self_attn"),
+                               (use_attention_tracing and traces is not None, "self_attn")):
+                if flag:
+                    raise UnboundLocalError("local variable %r referenced before assignment (the %s backbone has no "
+                                            "attention hook, P/src/model.py:864-872)" % (name, self.backbone_type))
         if cleaning_type is not None:
             # P/src/model.py:879-922: every patch token goes through the memory-bank projection and ctx_cleaner (before
             # or after it); the cleaned, projected tokens REPLACE x_norm_patchtokens, and the patch / box captions
@@ -510,7 +544,7 @@ class Patchioner(nn.Module):
         if single:
             return eng.region_reduce(tokens, single_map, None, 1.0)
         idx = torch.arange(B, dtype=torch.int32).repeat_interleave(NB)
-        return eng.region_reduce(tokens, weights, idx, 1.0).view(B, NB, self.embed_dim)
+        return eng.region_reduce(tokens, weights, idx, 1.0).view(B, NB, self.token_dim)
 
     def _bbox_feats_double_dino(self, tokens, bboxes, use_cls, return_type, variance):
         """extract_bboxes_feats_double_dino (P/src/bbox_utils.py:300-403).  The reference floor-divides a CLONE of the

@@ -12,9 +12,18 @@ _MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(3, 1, 1)
 _STD = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(3, 1, 1)
 
 
-def _to_tensor_normalized(img) -> torch.Tensor:
+# OpenAI-CLIP statistics, the transforms of the reference's timm CLIP backbones (P/src/model.py:377-391)
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def _to_tensor_normalized(img, mean=_MEAN, std=_STD) -> torch.Tensor:
     arr = np.asarray(img.convert("RGB"), dtype=np.uint8).transpose(2, 0, 1).astype(np.float32) / 255.0
-    return torch.from_numpy((arr - _MEAN) / _STD)
+    return torch.from_numpy((arr - mean) / std)
+
+
+def _stat(v):
+    return np.array(v, dtype=np.float32).reshape(3, 1, 1)
 
 
 def center_crop_origin(w: int, h: int, crop: int):
@@ -32,8 +41,9 @@ def center_crop_origin(w: int, h: int, crop: int):
 class ResizeCropTransform:
     """T.Compose([T.Resize(resize_dim, BICUBIC), T.CenterCrop(crop_dim), T.ToTensor(), T.Normalize(...)])"""
 
-    def __init__(self, resize_dim: int, crop_dim: int):
+    def __init__(self, resize_dim: int, crop_dim: int, mean=None, std=None):
         self.resize_dim, self.crop_dim = resize_dim, crop_dim
+        self.mean, self.std = (_MEAN if mean is None else _stat(mean)), (_STD if std is None else _stat(std))
 
     def __call__(self, img) -> torch.Tensor:
         from PIL import Image
@@ -47,22 +57,23 @@ class ResizeCropTransform:
         left, top = center_crop_origin(nw, nh, self.crop_dim)
         c = self.crop_dim
         img = img.crop((left, top, left + c, top + c))      # PIL fills with zeros outside the image = the pad
-        return _to_tensor_normalized(img)
+        return _to_tensor_normalized(img, self.mean, self.std)
 
 
 class SquareResizeTransform:
     """T.Compose([T.Resize((resize_dim, resize_dim), BICUBIC), T.ToTensor(), T.Normalize(...)])"""
 
-    def __init__(self, resize_dim: int):
+    def __init__(self, resize_dim: int, mean=None, std=None):
         self.resize_dim = resize_dim
+        self.mean, self.std = (_MEAN if mean is None else _stat(mean)), (_STD if std is None else _stat(std))
 
     def __call__(self, img) -> torch.Tensor:
         from PIL import Image
-        return _to_tensor_normalized(img.resize((self.resize_dim, self.resize_dim), Image.BICUBIC))
+        return _to_tensor_normalized(img.resize((self.resize_dim, self.resize_dim), Image.BICUBIC), self.mean, self.std)
 
 
-def make_transforms(resize_dim: int, crop_dim: int):
-    return ResizeCropTransform(resize_dim, crop_dim), SquareResizeTransform(resize_dim)
+def make_transforms(resize_dim: int, crop_dim: int, mean=None, std=None):
+    return ResizeCropTransform(resize_dim, crop_dim, mean, std), SquareResizeTransform(resize_dim, mean, std)
 
 
 def process_bboxes(imgs, bboxes, transform) -> torch.Tensor:

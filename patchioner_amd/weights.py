@@ -73,6 +73,57 @@ def synth_dinov2(seed: int, dino_model: str = "dinov2_vitb14_reg", depth: int | 
     return w
 
 
+CLIP_ARCHS = {
+    # timm model name fragment -> (embed_dim, depth, heads, patch, head width)
+    "vit_base_patch16_clip_224": (768, 12, 12, 16, 512),
+    "vit_base_patch32_clip_224": (768, 12, 12, 32, 512),
+    "vit_large_patch14_clip_224": (1024, 24, 16, 14, 768),
+}
+
+
+def clip_arch(name: str):
+    for k, v in CLIP_ARCHS.items():
+        if k in name:
+            return v
+    raise ValueError("unsupported OpenAI-CLIP timm model name %r" % (name,))
+
+
+def synth_clip_vit(seed: int, name: str = "vit_base_patch16_clip_224.openai", depth: int | None = None,
+                   img: int = 224) -> Dict[str, torch.Tensor]:
+    """State dict shaped like ``timm.create_model(name, act_layer=QuickGELU).state_dict()`` (P/src/model.py:371): the OpenAI
+    CLIP vision tower in timm's VisionTransformer layout -- bias-free patch conv, cls token, learned positions for
+    [cls | patches], norm_pre, pre-LN blocks without LayerScale, final norm, bias-free head to the joint space."""
+    D, full_depth, _, p, out = clip_arch(name)
+    depth = depth or full_depth
+    n = img // p
+    g = torch.Generator().manual_seed(seed)
+    w: Dict[str, torch.Tensor] = {}
+    w["cls_token"] = _tn(g, (1, 1, D), 0.02)
+    w["pos_embed"] = _tn(g, (1, 1 + n * n, D), 0.02)
+    w["patch_embed.proj.weight"] = _tn(g, (D, 3, p, p), 0.02)
+    w["norm_pre.weight"] = 0.5 + torch.rand(D, generator=g)
+    w["norm_pre.bias"] = _tn(g, (D,), 0.02)
+    for i in range(depth):
+        q = "blocks.%d." % i
+        for ln in ("norm1", "norm2"):
+            w[q + ln + ".weight"] = 0.5 + torch.rand(D, generator=g)
+            w[q + ln + ".bias"] = _tn(g, (D,), 0.02)
+        qkv = _tn(g, (3 * D, D), 0.02)
+        qkv[: 2 * D] *= 2.5
+        w[q + "attn.qkv.weight"] = qkv
+        w[q + "attn.qkv.bias"] = _tn(g, (3 * D,), 0.02)
+        w[q + "attn.proj.weight"] = _tn(g, (D, D), 0.02) * 0.3        # no LayerScale: small branch outputs keep the stream tame
+        w[q + "attn.proj.bias"] = _tn(g, (D,), 0.02)
+        w[q + "mlp.fc1.weight"] = _tn(g, (4 * D, D), 0.02)
+        w[q + "mlp.fc1.bias"] = _tn(g, (4 * D,), 0.02)
+        w[q + "mlp.fc2.weight"] = _tn(g, (D, 4 * D), 0.02) * 0.3
+        w[q + "mlp.fc2.bias"] = _tn(g, (D,), 0.02)
+    w["norm.weight"] = 0.5 + torch.rand(D, generator=g)
+    w["norm.bias"] = _tn(g, (D,), 0.02)
+    w["head.weight"] = _tn(g, (out, D), 0.03)
+    return w
+
+
 def add_outlier_channels(w: Dict[str, torch.Tensor], channels=(7, 300, 611), block: int = 1, gain: float = 4000.0,
                          hidden_rows=(11, 2000), hidden_gain: float = 30.0) -> Dict[str, torch.Tensor]:
     """DINOv2-like massive activations for stress tests: the MLP branch of ``block`` is multiplied by ``gain`` on a few

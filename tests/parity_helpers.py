@@ -6,41 +6,64 @@ prefix itself differs from the fp32 path's by the stated ViT tolerance, and an a
 while its top-2 logit margin exceeds what that perturbation moves the logits by.  So a caption is accepted iff
 
   (1) the HIP ids equal the oracle decoder's ids on the HIP path's OWN prefix, bit for bit, and
-  (2) either they also equal the reference ids, or at the FIRST step where they depart from the reference (identical
-      history up to there) the oracle's top-2 logit margin on that prefix is at most MARGIN_BOUND.
+  (2) either they also equal the reference ids, or at the FIRST step t where they depart from the reference (identical
+      history up to there) the departure is EXPLAINED by the prefix perturbation:
+        (a) derived bound, whenever the fp32 path's prefixes are available (``ref_prefixes``): with L_hip / L_ref the oracle's
+            logits at step t on the HIP prefix / on the fp32 prefix (same history), an arg-max can differ only if the
+            reference's top-2 margin is at most 2 max_v |L_hip[v] - L_ref[v]| (each logit moved by at most that
+            maximum; the two leaders can have approached each other by twice it).  The test asserts exactly that, with
+            the measured perturbation -- nothing is assumed about its size;
+        (b) otherwise (fixtures of the imported reference, whose prefixes were not kept): a fixed MARGIN_BOUND = 1e-3 logit
+            units on the oracle's top-2 margin at that step.  Logits span about +-4 and the fixtures' median top-2 margin
+            is 0.5; the largest margin at any departure observed over the ~800 captions of the suite is 1.8e-4 (round 2:
+            1.8e-4 and 6.7e-5), so 1e-3 leaves a factor 5 for other boxes / seeds and is 5x tighter than round 2's 0.005.
 
-No test accepts a fraction of wrong captions: every departure has to be explained by (2), one by one.
-MARGIN_BOUND = 0.005 logit units against logits spanning about +-4 (fixtures' median top-2 margin: 0.5): the projection
-softmax at temperature 0.01 multiplies the backbone's 6e-4 relative token error by up to 100 before it reaches the
-decoder prefix.  Every test prints the largest margin at a departure; over the 770 captions of the round-2 suite there were 2
-departures, at margins of 1.8e-4 and 6.7e-5 (27x below the bound).
+No test accepts a fraction of wrong captions: every departure has to be explained, one by one.  The backbone-free bit-exact
+statement of the whole path is tests/test_gpu_parity.py::test_e2e_fp32_backbone_mode_is_bit_exact_to_the_reference_fixture
+(``vit_dtype="fp32"``: no clause at all).
 """
 import torch
 
-MARGIN_BOUND = 0.005
+MARGIN_BOUND = 1e-3
 
 
-def assert_ids_explained(dec_oracle, gpu_log, ref_ids, label=""):
+def assert_ids_explained(dec_oracle, gpu_log, ref_ids, label="", ref_prefixes=None):
     """gpu_log: Patchioner.call_log entries (prefix [n, E] cuda, ids [n, 30] cuda); ref_ids: list of [n_i, 30] integer
-    arrays / tensors in the same row order (the reference's or the oracle's ids through the fp32 backbone).
+    arrays / tensors in the same row order (the reference's or the oracle's ids through the fp32 backbone); ref_prefixes:
+    the fp32 path's decoder inputs in the same order (PatchionerOracle.prefix_log), or None.
     Returns (identical captions, total)."""
     P = torch.cat([p for p, _ in gpu_log]).float().cpu()
     G = torch.cat([i for _, i in gpu_log]).cpu().long()
     R = torch.cat([torch.as_tensor(r).long().reshape(-1, G.shape[1]) for r in ref_ids])
     assert G.shape == R.shape, (label, G.shape, R.shape)
+    RP = None
+    if ref_prefixes is not None:
+        RP = torch.cat([torch.as_tensor(p).float().reshape(-1, P.shape[1]) for p in ref_prefixes])
+        assert RP.shape == P.shape, (label, RP.shape, P.shape)
     keep = torch.isfinite(P).all(dim=1)          # NaN prefixes (dummy boxes): the reference decodes garbage from NaN as well
     o_ids, _, o_margin = dec_oracle.decode_ids(P[keep], cached=True)     # same sums, keys/values kept (test_oracle_golden pins it)
     assert torch.equal(G[keep], o_ids), "%s: decoder ids differ from the oracle on identical prefixes" % label
-    Gk, Rk = G[keep], R[keep]
+    Gk, Rk, Pk = G[keep], R[keep], P[keep]
+    RPk = RP[keep] if RP is not None else None
     worst, departed = 0.0, 0
     for r in (Gk != Rk).any(dim=1).nonzero().flatten().tolist():
         t = int((Gk[r] != Rk[r]).nonzero()[0])
-        m = float(o_margin[r, t])
-        worst = max(worst, m)
         departed += 1
-        assert m <= MARGIN_BOUND, ("%s: caption %d departs from the reference at step %d where the top-2 margin is %.3e "
-                                   "(> %.2e): not a near-tie" % (label, r, t, m, MARGIN_BOUND))
+        if RPk is not None:
+            hist = Rk[r, :t]
+            l_hip, l_ref = dec_oracle.logits_after(Pk[r], hist), dec_oracle.logits_after(RPk[r], hist)
+            top2 = l_ref.topk(2).values
+            m, moved = float(top2[0] - top2[1]), float((l_hip - l_ref).abs().max())
+            worst = max(worst, m)
+            assert m <= 2.0 * moved, ("%s: caption %d departs from the reference at step %d where the reference's top-2 margin is "
+                                      "%.3e but the prefix perturbation moves the logits by at most %.3e: not explained"
+                                      % (label, r, t, m, moved))
+        else:
+            m = float(o_margin[r, t])
+            worst = max(worst, m)
+            assert m <= MARGIN_BOUND, ("%s: caption %d departs from the reference at step %d where the top-2 margin is %.3e "
+                                       "(> %.2e): not a near-tie" % (label, r, t, m, MARGIN_BOUND))
     total = int(keep.sum())
-    print("%s: %d / %d captions identical to the reference; %d departures, largest top-2 margin at a departure %.2e"
-          % (label, total - departed, total, departed, worst))
+    print("%s: %d / %d captions identical to the reference; %d departures, largest top-2 margin at a departure %.2e (%s bound)"
+          % (label, total - departed, total, departed, worst, "derived" if RPk is not None else "fixed 1e-3"))
     return total - departed, total

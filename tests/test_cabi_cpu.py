@@ -90,7 +90,12 @@ def test_out_of_scope_options_raise():
     with pytest.raises(NotImplementedError):
         Patchioner.from_config(dict(base, dino_model="dinov2_vitb14_reg", clipcap={"x": 1}), device="cuda")
     with pytest.raises(ValueError):
-        Patchioner.from_config(dict(base, dino_model="vit_base_patch16_clip_224.openai"), device="cuda")
+        Patchioner.from_config(dict(base, dino_model="RN50x4"), device="cuda")
+    with pytest.raises(ValueError):
+        Patchioner.from_config(dict(base, dino_model="dinov2_vitl14_reg_dinotxt"), device="cuda")
+    with pytest.raises(NotImplementedError):     # the CLIP ViT variant is served at its native 224 x 224 only
+        Patchioner.from_config(dict(base, dino_model="vit_base_patch16_clip_224.openai", prefix_size=512, resize_dim=336,
+                                    crop_dim=336), device="cuda")
     with pytest.raises(Exception, match="projection_type"):
         Patchioner.from_config({"prefix_size": 768, "support_memory_size": 10, "decap_weights": "x.pt",
                                 "dino_model": "dinov2_vitb14_reg", "projection_type": "nonsense"}, device="cuda")

@@ -55,11 +55,11 @@ def test_config3_518_boxes_16_regions(O):
     ref = O.extract_bboxes_feats(tokens[:, 5:].cpu(), boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=1.0)
     np.testing.assert_allclose(feats.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-6)
 
-    m.call_log, orc.call_log = [], []
+    m.call_log, orc.call_log, orc.prefix_log = [], [], []
     got = m(imgs.cuda(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=1.0)
     want = orc.forward(imgs.clone(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=1.0)
     assert len(got["bbox_capts"]) == B and all(len(r) == NB for r in got["bbox_capts"])
-    _, total = assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "config3 (518^2, 16 boxes)")
+    _, total = assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "config3 (518^2, 16 boxes)", ref_prefixes=orc.prefix_log)
     assert total == B * NB
 
 
@@ -76,11 +76,11 @@ def test_config4_capdec_dense_boxes_chunked(O):
     b = np.concatenate([xy, wh], -1).astype(np.float32)
     b[:, -3:] = [0.0, 0.0, 1.0, 1.0]                       # padding boxes of the dense-captioning driver
     boxes = torch.tensor(b)
-    m.call_log, orc.call_log = [], []
+    m.call_log, orc.call_log, orc.prefix_log = [], [], []
     got = m(imgs.cuda(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=0.5)
     want = orc.forward(imgs.clone(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=0.5)
     assert len(sum(got["bbox_capts"], [])) == len(sum(want["bbox_capts"], [])) == B * NB
-    assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "config4 (CapDec, dense boxes)")
+    assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "config4 (CapDec, dense boxes)", ref_prefixes=orc.prefix_log)
     # (the decoder stage alone on identical prefixes, bit-exact for all 144, is clause (1) of assert_ids_explained above)
     # config 4's multi-GPU driver on the real model (no process group = one shard; the 2-rank sharding itself is tested with
     # gloo in tests/test_dist_cpu.py): nested [B][NB] captions of the forward, the caller's boxes floor-divided in place
@@ -127,13 +127,13 @@ def test_nested_caption_outputs_heads_patches_registers(O):
     orc = _oracle_for(O, crop, True)
     imgs = W.synth_images(12, B, crop)
     kw = dict(get_cls_capt=False, get_attn_heads_capt=True, get_patch_capts=True, get_register_capts=True)
-    m.call_log, orc.call_log = [], []
+    m.call_log, orc.call_log, orc.prefix_log = [], [], []
     got = m(imgs.cuda(), **kw)
     want = orc.forward(imgs.clone(), **kw)
     assert set(got) == set(want) == {"attn_heads_capts", "patch_tokens_capts", "register_capts"}
     for key, per in (("attn_heads_capts", 16), ("patch_tokens_capts", 256), ("register_capts", 4)):
         assert len(got[key]) == B and all(len(r) == per for r in got[key])
-    _, total = assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "nested outputs (heads, patches, registers)")
+    _, total = assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "nested outputs (heads, patches, registers)", ref_prefixes=orc.prefix_log)
     assert total == B * (16 + 256 + 4)
 
 
@@ -258,10 +258,10 @@ def test_vits14_backbone_readout_and_captions(O, golden):
     assert err <= 4e-3
     orc = O.PatchionerOracle(vit, O.DeCapOracle(dec), bank, ClipDetokenizer().decode, crop_dim=224, num_attn_heads=6)
     kw = dict(get_cls_capt=True, get_avg_self_attn_capt=True, traces=[gc.block_trace(3, 4), gc.block_trace(9, 2), gc.block_trace(0, 12)])
-    m.call_log, orc.call_log = [], []
+    m.call_log, orc.call_log, orc.prefix_log = [], [], []
     got, want = m(imgs.cuda(), **kw), orc.forward(imgs.clone(), **kw)
     assert set(got) == set(want)
-    _, total = assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "ViT-S/14 DeCap path")
+    _, total = assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "ViT-S/14 DeCap path", ref_prefixes=orc.prefix_log)
     assert total == 9
 
 
@@ -290,11 +290,11 @@ def test_ctx_cleaner_kernel_and_forward(O, golden):
     for ct, after, cf in (("orthogonal_projection", True, "cls"), ("contrastive_mask", False, "avg_self_attn")):
         kw = dict(get_cls_capt=True, bboxes=None, cleaning_type=ct, clean_after_projection=after, alpha=0.8, clean_from=cf,
                   gaussian_avg=True, gaussian_bbox_variance=0.5)
-        m.call_log, orc.call_log = [], []
+        m.call_log, orc.call_log, orc.prefix_log = [], [], []
         got = m(imgs.cuda(), **{**kw, "bboxes": boxes.clone()})
         want = orc.forward(imgs.clone(), **{**kw, "bboxes": boxes.clone()})
         assert len(got["cls_capt"] + sum(got["bbox_capts"], [])) == len(want["cls_capt"] + sum(want["bbox_capts"], [])) == 10
-        _, total = assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "cleaning %s after=%s from=%s" % (ct, after, cf))
+        _, total = assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "cleaning %s after=%s from=%s" % (ct, after, cf), ref_prefixes=orc.prefix_log)
         assert total == 10
 
 
@@ -368,7 +368,7 @@ def test_caption_bboxes_crop_and_recaption_vs_oracle(O):
                                   no_crop=not crop_boxes)
         assert torch.equal(dev.cpu(), crops), "device transform of the crops differs from the host transform"
         for capt_type in ("cls_capt", "avg_self_attn_capt"):
-            m.call_log, orc.call_log = [], []
+            m.call_log, orc.call_log, orc.prefix_log = [], [], []
             got = m.caption_bboxes(imgs, boxes.clone(), capt_type=capt_type, crop_boxes=crop_boxes)
             bs, nb = len(imgs), boxes.shape[1]
             want = []
@@ -377,7 +377,7 @@ def test_caption_bboxes_crop_and_recaption_vs_oracle(O):
                 want += orc.forward(crops[s:e].clone(), get_cls_capt=capt_type == "cls_capt",
                                     get_avg_self_attn_capt=capt_type == "avg_self_attn_capt")[capt_type]
             assert set(got) == {"bbox_capts"} and [len(r) for r in got["bbox_capts"]] == [nb] * bs
-            _, total = assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "caption_bboxes crop=%s %s" % (crop_boxes, capt_type))
+            _, total = assert_ids_explained(orc.decoder, m.call_log, orc.call_log, "caption_bboxes crop=%s %s" % (crop_boxes, capt_type), ref_prefixes=orc.prefix_log)
             assert total == bs * nb
     m.call_log = None
     with pytest.raises(KeyError):                             # the reference never asks forward() for the scores it then reads
@@ -442,3 +442,55 @@ def test_vit_80_images_per_launch_rolling_gemm_is_bitwise_the_16_image_launches(
     tok_b2, _ = big.vit_forward(imgs)                 # and the same bits again (a race would not reproduce)
     assert torch.equal(tok_b, tok_b2)
     big.close(); small.close()
+
+
+def test_clip_vit_backbone_decap_original_config(O):
+    """The reference's "DeCap original" configuration (P/configs/decap_B16.k.yaml: dino_model vit_base_patch16_clip_224.openai,
+    prefix_size 512, normalize False; P/src/model.py:358-392, 786-796, 864-865): timm OpenAI-CLIP ViT with QuickGELU, norm_pre,
+    no LayerScale, the 768 -> 512 head on every token, CLIP image statistics, memory bank L2-normalised at load
+    (model.py:174), no attention hook.  cls / gaussian-box / trace captions against the oracle (ClipViTOracle, itself held to
+    HF's CLIPVisionModelWithProjection in the CPU suite); options that need the hook fail as in the reference."""
+    from patchioner_amd import Patchioner
+    from patchioner_amd.tokenizer import ClipDetokenizer
+    name = "vit_base_patch16_clip_224.openai"
+    vit_sd, dec_sd = W.synth_clip_vit(31, name, depth=2), W.synth_decap(33, prefix_size=512)
+    bank = W.synth_bank(35, 2048, 512) * 3.0                   # not unit-norm: the load-time normalisation must happen
+    cfg = {"decap_weights": dec_sd, "prefix_size": 512, "support_memory_size": 2048, "dino_model": name, "normalize": False,
+           "resize_dim": 224, "crop_dim": 224, "clip_model_name": "ViT-B/16", "use_talk2dino_project": False,
+           "dino_weights": vit_sd, "memory_bank": bank.clone(), "max_batch": 4}
+    m = Patchioner.from_config(cfg, device="cuda")
+    assert (m.backbone_type, m.patch_size, m.num_tokens, m.embed_dim, m.num_global_tokens) == ("CLIP", 16, 197, 768, 1)
+    dec = O.DeCapOracle(dec_sd)
+    vit = O.ClipViTOracle(vit_sd, num_heads=12, patch_size=16)
+    orc = O.PatchionerOracle(vit, dec, bank / bank.norm(dim=-1, keepdim=True), ClipDetokenizer().decode, normalize=False, crop_dim=224)
+    imgs = W.synth_images(37, 3, 224)
+    tokens, qkv = m.engine.vit_forward(imgs, want_qkv=False)
+    d = vit(imgs)
+    ref = torch.cat([d["x_norm_clstoken"][:, None], d["x_norm_patchtokens"]], 1)
+    err = float((tokens.cpu() - ref).abs().max() / ref.abs().max())
+    print("CLIP ViT-B/16 depth 2: tokens rel-max-err %.2e" % err)
+    assert qkv is None and tokens.shape == (3, 197, 512) and err <= 4e-3
+    rng = np.random.RandomState(9)
+    xy = rng.randint(0, 10, size=(3, 4, 2)) * 16.0
+    wh = rng.randint(1, 5, size=(3, 4, 2)) * 16.0 + rng.randint(0, 16, size=(3, 4, 2))
+    boxes = torch.tensor(np.concatenate([xy, wh], -1), dtype=torch.float32)
+    traces = [[{"x": 0.1 + 0.05 * i, "y": 0.2 + 0.04 * i} for i in range(8)], gc.block_trace(3, 7), gc.block_trace(9, 2)]
+    kw = dict(get_cls_capt=True, traces=traces, gaussian_avg=True, gaussian_bbox_variance=1.0)
+    m.call_log, orc.call_log, orc.prefix_log = [], [], []
+    mine = boxes.clone()
+    got = m(imgs.cuda(), bboxes=mine, **kw)
+    want = orc.forward(imgs.clone(), bboxes=boxes.clone(), **kw)
+    assert torch.equal(mine, boxes // 16)                          # bboxes //= patch_size on the caller's tensor (bbox_utils.py:19)
+    assert set(got) == set(want) == {"cls_capt", "bbox_capts", "trace_capts"}
+    _, total = assert_ids_explained(dec, m.call_log, orc.call_log, "CLIP ViT-B/16 (decap_B16)", ref_prefixes=orc.prefix_log)
+    assert total == 3 + 12 + 3
+    for bad in (dict(get_avg_self_attn_capt=True), dict(get_attn_heads_capt=True), dict(traces=traces, use_attention_tracing=True)):
+        with pytest.raises(UnboundLocalError):                     # model.py:864-872: never assigned without the hook
+            m(imgs.cuda(), get_cls_capt=False, **bad)
+    # the image transforms carry CLIP's statistics (model.py:377-391), on the host mirror and on the device
+    from PIL import Image
+    raw = gc.prep_image(301, 320, 256)
+    host = m.image_transforms(Image.fromarray(raw))
+    assert torch.equal(m.preprocess_images([raw]).cpu()[0], host)
+    assert abs(float(host.mean()) - float((torch.from_numpy(np.asarray(Image.fromarray(raw).resize((280, 224), Image.BICUBIC).crop((28, 0, 252, 224)), dtype=np.float32).transpose(2, 0, 1) / 255.0)
+                                           - torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(3, 1, 1)).div(torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(3, 1, 1)).mean())) < 1e-4

@@ -174,9 +174,9 @@ def test_config4_per_gpu_shard_full_size(O):
     b[:, -1] = [0.0, 0.0, 1.0, 1.0]                       # the dense-captioning driver's padding box
     boxes = torch.tensor(b)
     _stagewise_checks(O, m, None, imgs.cuda(), boxes, 0.5, "config 4")
-    m.call_log, orc.call_log = [], []
+    m.call_log, orc.call_log, orc.prefix_log = [], [], []
     got = m(imgs.cuda(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=0.5)
     want = orc.forward(imgs.clone(), get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=0.5)
     assert [len(r) for r in got["bbox_capts"]] == [len(r) for r in want["bbox_capts"]] == [8] * 8
-    assert_ids_explained(dec, m.call_log, orc.call_log, "config 4 shard (8 x 8 boxes, CapDec, depth 12)")
+    assert_ids_explained(dec, m.call_log, orc.call_log, "config 4 shard (8 x 8 boxes, CapDec, depth 12)", ref_prefixes=orc.prefix_log)
     m.engine.close()

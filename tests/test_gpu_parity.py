@@ -480,11 +480,11 @@ def test_e2e_full_depth_ids_vs_oracle(O, with_bank):
     boxes = gc.e2e_boxes()
     kw = dict(get_cls_capt=True, get_avg_self_attn_capt=True, traces=traces, use_attention_tracing=True, gaussian_avg=True,
               gaussian_bbox_variance=1.0)
-    m.call_log, orc.call_log = [], []
+    m.call_log, orc.call_log, orc.prefix_log = [], [], []
     got = m(imgs.cuda(), bboxes=boxes.clone(), **kw)
     want = orc.forward(imgs.clone(), bboxes=boxes.clone(), **kw)
     assert set(got) == set(want) and all(len(got[k]) == len(want[k]) for k in want)
-    same, total = assert_ids_explained(dec, m.call_log, orc.call_log, "depth-12 e2e (bank=%s)" % with_bank)
+    same, total = assert_ids_explained(dec, m.call_log, orc.call_log, "depth-12 e2e (bank=%s)" % with_bank, ref_prefixes=orc.prefix_log)
     assert total == 4 * 3 + boxes.shape[0] * boxes.shape[1]
 
 

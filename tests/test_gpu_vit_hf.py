@@ -67,3 +67,51 @@ def test_hip_vit_outlier_channels_vs_hf_port(golden, size, stride, dtype, tol):
     err_small = float((cmp[..., keep] - ref[..., keep]).abs().max() / ref[..., keep].abs().max())
     print("HF outliers %d^2 [%s]: rel-max-err %.2e (other channels %.2e), min cosine %.6f" % (size, dtype, err, err_small, cos))
     assert err <= tol and err_small <= 2 * tol and cos >= 1 - 4 * tol * tol
+
+
+@pytest.mark.parametrize("tag,name,D,heads,depth", [("vitl", "dinov2_vitl14_reg", 1024, 16, 24), ("vits", "dinov2_vits14_reg", 384, 6, 12)])
+def test_hip_vit_other_sizes_vs_hf_port(golden, tag, name, D, heads, depth):
+    """ViT-L/14-reg at depth 24 (BASELINE config 5's backbone) and ViT-S/14-reg at depth 12, directly against the HF port's
+    outputs (tests/golden/vit_hf_variants.npz): row a2's pin no longer stops at ViT-B."""
+    from patchioner_amd.engine import Engine
+    g = golden("vit_hf_variants")
+    e = Engine(embed_dim=D, depth=depth, num_heads=heads, num_registers=4, crop_dim=224, max_batch=2, vit_dtype="fp16",
+               readout_heads=16 if D != 384 else 6)
+    try:
+        e.load_state_dict(W.synth_dinov2(85, name, depth=depth))
+        e.finalize()
+        got, _ = e.vit_forward(W.synth_images(86, 2, 224), want_qkv=False)
+        got = got.cpu()
+    finally:
+        e.close()
+    ref = torch.cat([torch.from_numpy(g["%s_global" % tag]), torch.from_numpy(g["%s_patch_sample" % tag])], 1)
+    cmp = torch.cat([got[:, :5], got[:, 5::7]], 1)
+    assert cmp.shape == ref.shape and torch.isfinite(got).all()
+    err = float((cmp - ref).abs().max() / ref.abs().max())
+    print("HF %s depth %d: rel-max-err %.2e" % (tag, depth, err))
+    assert err <= 4e-3
+
+
+@pytest.mark.parametrize("tag,name,patch,stride", [("b16", "vit_base_patch16_clip_224.openai", 16, 5), ("b32", "vit_base_patch32_clip_224.openai", 32, 1)])
+@pytest.mark.parametrize("dtype,tol", [("fp16", 4e-3), ("bf16", 3e-2)])
+def test_hip_clip_vit_depth12_vs_hf_clip(golden, tag, name, patch, stride, dtype, tol):
+    """The OpenAI-CLIP ViT variant (P/src/model.py:358-392, 786-796): patch 16 / 32, norm_pre, QuickGELU, no LayerScale, final
+    norm + bias-free 768 -> 512 head on every token -- the HIP path against transformers.CLIPVisionModelWithProjection."""
+    from patchioner_amd.engine import Engine
+    g = golden("clip_vit_hf")
+    n = 224 // patch
+    e = Engine(embed_dim=768, depth=12, num_heads=12, num_registers=0, crop_dim=224, patch_size=patch, pretrain_grid=n,
+               max_batch=2, vit_dtype=dtype, vit_arch="clip", vit_out_dim=512, vit_ln_eps=1e-5, prefix_size=512)
+    try:
+        e.load_state_dict(W.synth_clip_vit(87, name, depth=12))
+        e.finalize()
+        got, _ = e.vit_forward(W.synth_images(88, 2, 224), want_qkv=False)
+        got = got.cpu()
+    finally:
+        e.close()
+    assert got.shape == (2, 1 + n * n, 512) and torch.isfinite(got).all()
+    ref = torch.cat([torch.from_numpy(g["%s_cls" % tag])[:, None], torch.from_numpy(g["%s_patch_sample" % tag])], 1)
+    cmp = torch.cat([got[:, :1], got[:, 1::stride]], 1)
+    err = float((cmp - ref).abs().max() / ref.abs().max())
+    print("HF CLIP %s [%s]: rel-max-err %.2e" % (tag, dtype, err))
+    assert err <= tol

@@ -268,10 +268,10 @@ def gen_e2e(ref):
     save("e2e", **arrs)
 
 
-def _hf_dinov2(w, depth):
+def _hf_dinov2(w, depth, hidden=768, heads=12):
     """transformers.Dinov2WithRegistersModel (the independent port) carrying OUR state dict ``w``."""
     from transformers import Dinov2WithRegistersConfig, Dinov2WithRegistersModel
-    cfg = Dinov2WithRegistersConfig(hidden_size=768, num_hidden_layers=depth, num_attention_heads=12, mlp_ratio=4,
+    cfg = Dinov2WithRegistersConfig(hidden_size=hidden, num_hidden_layers=depth, num_attention_heads=heads, mlp_ratio=4,
                                     image_size=518, patch_size=14, num_register_tokens=4, layerscale_value=1.0,
                                     hidden_act="gelu", qkv_bias=True, use_swiglu_ffn=False, layer_norm_eps=1e-6,
                                     attn_implementation="eager")
@@ -341,6 +341,65 @@ def gen_vit_hf12():
     save("vit_hf_depth12", **arrs)
 
 
+def gen_vit_hf_variants():
+    """The HF port at the OTHER backbone sizes the build serves: ViT-L/14-reg at its full depth 24 (BASELINE config 5's
+    backbone) and ViT-S/14-reg at depth 12, 224^2 (tests/test_gpu_vit_hf.py holds the HIP ViT to them)."""
+    arrs = {}
+    for tag, name, hidden, heads, depth in (("vitl", "dinov2_vitl14_reg", 1024, 16, 24), ("vits", "dinov2_vits14_reg", 384, 6, 12)):
+        m = _hf_dinov2(W.synth_dinov2(85, name, depth=depth), depth, hidden, heads)
+        out = _hf_forward(m, W.synth_images(86, 2, 224))
+        arrs["%s_global" % tag] = out[:, :5]
+        arrs["%s_patch_sample" % tag] = out[:, 5::7]
+        arrs["%s_absmax" % tag] = out.abs().max()
+    save("vit_hf_variants", **arrs)
+
+
+def _hf_clip(w, depth, patch, heads=12):
+    """transformers.CLIPVisionModelWithProjection (an independent implementation of the OpenAI vision tower) carrying a
+    timm-named state dict ``w`` (weights.synth_clip_vit)."""
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    D, out = w["cls_token"].shape[-1], w["head.weight"].shape[0]
+    cfg = CLIPVisionConfig(hidden_size=D, intermediate_size=4 * D, num_hidden_layers=depth, num_attention_heads=heads,
+                           image_size=224, patch_size=patch, projection_dim=out, hidden_act="quick_gelu",
+                           layer_norm_eps=1e-5, attn_implementation="eager")
+    m = CLIPVisionModelWithProjection(cfg).eval()
+    sd = {"vision_model.embeddings.class_embedding": w["cls_token"].reshape(-1),
+          "vision_model.embeddings.position_embedding.weight": w["pos_embed"].reshape(-1, D),
+          "vision_model.embeddings.patch_embedding.weight": w["patch_embed.proj.weight"],
+          "vision_model.pre_layrnorm.weight": w["norm_pre.weight"], "vision_model.pre_layrnorm.bias": w["norm_pre.bias"],
+          "vision_model.post_layernorm.weight": w["norm.weight"], "vision_model.post_layernorm.bias": w["norm.bias"],
+          "visual_projection.weight": w["head.weight"]}
+    for i in range(depth):
+        s, t = "blocks.%d." % i, "vision_model.encoder.layers.%d." % i
+        q, k, v = w[s + "attn.qkv.weight"].chunk(3, 0)
+        qb, kb, vb = w[s + "attn.qkv.bias"].chunk(3, 0)
+        for nm, ww, bb in (("q_proj", q, qb), ("k_proj", k, kb), ("v_proj", v, vb)):
+            sd[t + "self_attn.%s.weight" % nm], sd[t + "self_attn.%s.bias" % nm] = ww, bb
+        sd[t + "self_attn.out_proj.weight"], sd[t + "self_attn.out_proj.bias"] = w[s + "attn.proj.weight"], w[s + "attn.proj.bias"]
+        sd[t + "layer_norm1.weight"], sd[t + "layer_norm1.bias"] = w[s + "norm1.weight"], w[s + "norm1.bias"]
+        sd[t + "layer_norm2.weight"], sd[t + "layer_norm2.bias"] = w[s + "norm2.weight"], w[s + "norm2.bias"]
+        sd[t + "mlp.fc1.weight"], sd[t + "mlp.fc1.bias"] = w[s + "mlp.fc1.weight"], w[s + "mlp.fc1.bias"]
+        sd[t + "mlp.fc2.weight"], sd[t + "mlp.fc2.bias"] = w[s + "mlp.fc2.weight"], w[s + "mlp.fc2.bias"]
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    missing = [k for k in missing if "position_ids" not in k]
+    assert not missing and not unexpected, (missing, unexpected)
+    return m
+
+
+def gen_clip_hf():
+    """The CLIP ViT variant (P/src/model.py:358-392, 786-796): every token through HF's own post_layernorm and
+    visual_projection (HF applies them to the pooled cls only; the reference applies timm's norm + head to all tokens)."""
+    arrs = {}
+    for tag, name, patch, stride in (("b16", "vit_base_patch16_clip_224.openai", 16, 5), ("b32", "vit_base_patch32_clip_224.openai", 32, 1)):
+        m = _hf_clip(W.synth_clip_vit(87, name, depth=12), 12, patch)
+        hs = m.vision_model(pixel_values=W.synth_images(88, 2, 224)).last_hidden_state
+        out = m.visual_projection(m.vision_model.post_layernorm(hs))
+        arrs["%s_cls" % tag] = out[:, 0]
+        arrs["%s_patch_sample" % tag] = out[:, 1::stride]
+        arrs["%s_absmax" % tag] = out.abs().max()
+    save("clip_vit_hf", **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = refshim.load()
@@ -360,6 +419,8 @@ def main():
     if want("e2e"): gen_e2e(ref)
     if want("vit_hf"): gen_vit_hf()
     if want("vit_hf12"): gen_vit_hf12()
+    if want("vit_hf_variants"): gen_vit_hf_variants()
+    if want("clip_hf"): gen_clip_hf()
 
 
 if __name__ == "__main__":
