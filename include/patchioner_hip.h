@@ -68,7 +68,9 @@ typedef struct {
   int32_t max_batch;          /* images per pio_vit_forward call */
   int32_t max_prefixes;       /* prefixes per pio_decode_greedy / pio_mem_project call */
   int32_t max_steps;          /* decode steps (reference: 30) */
-  /* numerics of the ViT MFMA path: 0 = fp16 operands, 1 = bf16 operands (fp32 accumulate either way) */
+  /* numerics of the ViT MFMA path: 0 = fp16 operands, 1 = bf16 operands (fp32 accumulate either way); 2 = exact fp32
+   * operands on the fp32 MFMA, a PARITY mode (plain kernels, ~20x slower) in which the whole path is held to the fp32
+   * reference with no near-tie clause (csrc/vit_fp32.hip) */
   int32_t vit_operand_type;
   int32_t device;             /* HIP device ordinal */
   /* backbone family.  0: DINOv2 (torch.hub, P/src/model.py:342-343: LayerScale, exact-erf GELU, registers, interpolated

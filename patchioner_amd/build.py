@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libpatchioner_hip.so")
-SOURCES = ["api.cpp", "vit_gemm.hip", "vit_gemm256.hip", "vit_gemm_roll.hip", "vit_attention.hip", "vit_misc.hip", "region.hip", "project.hip", "decoder.hip", "viecap.hip", "preprocess.hip"]
+SOURCES = ["api.cpp", "vit_gemm.hip", "vit_gemm256.hip", "vit_gemm_roll.hip", "vit_attention.hip", "vit_fp32.hip", "vit_misc.hip", "region.hip", "project.hip", "decoder.hip", "viecap.hip", "preprocess.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function",
          "-I", INCLUDE, "-I", CSRC]

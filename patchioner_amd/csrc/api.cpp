@@ -92,6 +92,11 @@ struct pio_context {
   float* ones = nullptr;                         // CLIP: "LayerScale" of ones (x += 1 * branch is exact)
   float* tok_tmp = nullptr;                      // CLIP: final-norm tokens [max_batch * T][D] before the head
   int Dout = 0;                                  // width of the returned tokens
+  // exact-fp32 parity mode (vit_operand_type = 2, vit_fp32.hip): fp32 copies of the GEMM weights and fp32 activations
+  bool vit_f32 = false;
+  struct VitLayerF32 { float *qkvw, *projw, *fc1w, *fc2w; };
+  std::vector<VitLayerF32> vl32;
+  float *pe_w32 = nullptr, *f_ape = nullptr, *f_emb = nullptr, *f_xn = nullptr, *f_qkv = nullptr, *f_ao = nullptr, *f_h = nullptr;
   std::vector<VitLayerDev> vl;
   // ViT workspaces
   float* x = nullptr; void* xn = nullptr; void* ao = nullptr; void* hbuf = nullptr; void* ape = nullptr;
@@ -291,6 +296,27 @@ int finalize_vit(pio_context* c) {
       if ((rc = need(c, pre + w.key, {w.rows, w.cols}, &t))) return rc;
       if ((rc = upload_op(c, t->data.data(), w.rows, w.cols, w.cols, w.dst))) return rc;
     }
+    if (c->vit_f32) {
+      if ((int)c->vl32.size() != depth) c->vl32.resize(depth);
+      float** d32[] = {&c->vl32[l].qkvw, &c->vl32[l].projw, &c->vl32[l].fc1w, &c->vl32[l].fc2w};
+      for (int i = 0; i < 4; ++i) {
+        if ((rc = need(c, pre + ws[i].key, {ws[i].rows, ws[i].cols}, &t))) return rc;
+        if ((rc = upload_f32(c, t->data.data(), t->data.size(), d32[i]))) return rc;
+      }
+    }
+  }
+  if (c->vit_f32) {
+    if ((rc = need(c, "patch_embed.proj.weight", {D, 3, p, p}, &t))) return rc;
+    std::vector<float> pw((size_t)D * c->Kpad, 0.f);
+    for (int r = 0; r < D; ++r) memcpy(&pw[(size_t)r * c->Kpad], &t->data[(size_t)r * c->Kpe], (size_t)c->Kpe * 4);
+    if ((rc = upload_f32(c, pw.data(), pw.size(), &c->pe_w32))) return rc;
+    const size_t Bm = c->cfg.max_batch, Mm = Bm * c->Tp;
+    if ((rc = c->dmalloc(&c->f_ape, Bm * c->n2 * c->Kpad, true))) return rc;
+    if ((rc = c->dmalloc(&c->f_emb, Bm * c->n2 * D, true))) return rc;
+    if ((rc = c->dmalloc(&c->f_xn, Mm * D, true))) return rc;
+    if ((rc = c->dmalloc(&c->f_qkv, Mm * 3 * D, true))) return rc;
+    if ((rc = c->dmalloc(&c->f_ao, Mm * D, true))) return rc;
+    if ((rc = c->dmalloc(&c->f_h, Mm * 4 * D, true))) return rc;
   }
   // workspaces
   const size_t B = c->cfg.max_batch, M = B * c->Tp;
@@ -644,6 +670,7 @@ int pio_create(const pio_config* cfg, pio_handle* out) {
   c->Kpe = 3 * cfg->patch_size * cfg->patch_size;
   c->Kpad = round_up(c->Kpe, 64);
   c->op = cfg->vit_operand_type == 1 ? OP_BF16 : OP_F16;
+  c->vit_f32 = cfg->vit_operand_type == 2;
   c->Dout = cfg->vit_out_dim > 0 ? cfg->vit_out_dim : cfg->embed_dim;
   const char* ng = getenv("PIO_NO_GRAPH");
   c->use_graph = !(ng && ng[0] == '1');
@@ -821,6 +848,30 @@ int pio_set_memory_bank_device(pio_handle c, const float* dev_bank, int64_t rows
   return bank_common(c, rows, dim);
 }
 
+// The same block in exact fp32 (vit_fp32.hip; parity mode): LN -> qkv -> attention -> proj -> x += ls1 * branch -> LN -> fc1 ->
+// GELU -> fc2 -> x += ls2 * branch.  qkv_last: the fused-QKV output of the T valid rows of every image (the hook's tensor).
+static int run_vit_block_f32(pio_handle c, int l, int B, float* qkv_last, const int32_t* lens, hipStream_t s) {
+  const VitLayerDev& L = c->vl[l];
+  const pio_context::VitLayerF32& W = c->vl32[l];
+  const int D = c->D, M = B * c->Tp;
+  const float eps = c->cfg.vit_ln_eps;
+  HIP_OK(launch_layernorm_f32(c->x, L.n1w, L.n1b, eps, M, D, c->f_xn, s));
+  HIP_OK(launch_sgemm_tn(c->f_xn, D, W.qkvw, D, L.qkvb, 1.f, c->f_qkv, 3 * D, M, 3 * D, D, 0, 0, s));
+  if (qkv_last)
+    for (int b = 0; b < B; ++b)
+      HIP_OK(hipMemcpyAsync(qkv_last + (size_t)b * c->T * 3 * D, c->f_qkv + (size_t)b * c->Tp * 3 * D, (size_t)c->T * 3 * D * 4,
+                            hipMemcpyDeviceToDevice, s));
+  HIP_OK(launch_attention_f32(c->f_qkv, B, c->H, c->T, c->Tp, D, 0.125f, lens, c->f_ao, s));
+  HIP_OK(launch_sgemm_tn(c->f_ao, D, W.projw, D, L.projb, 1.f, c->f_xn, D, M, D, D, 0, 0, s));
+  HIP_OK(launch_resid_ls_f32(c->x, c->f_xn, L.ls1, (size_t)M * D, D, s));
+  HIP_OK(launch_layernorm_f32(c->x, L.n2w, L.n2b, eps, M, D, c->f_xn, s));
+  HIP_OK(launch_sgemm_tn(c->f_xn, D, W.fc1w, D, L.fc1b, 1.f, c->f_h, 4 * D, M, 4 * D, D, 0, 0, s));
+  HIP_OK(launch_gelu_f32(c->f_h, (size_t)M * 4 * D, c->cfg.vit_arch == 1 ? 1 : 0, s));
+  HIP_OK(launch_sgemm_tn(c->f_h, 4 * D, W.fc2w, 4 * D, L.fc2b, 1.f, c->f_xn, D, M, D, 4 * D, 0, 0, s));
+  HIP_OK(launch_resid_ls_f32(c->x, c->f_xn, L.ls2, (size_t)M * D, D, s));
+  return PIO_OK;
+}
+
 // One pre-LN DINOv2 block on the B sequences of c->x (in place): LN1 -> qkv -> attention -> proj (+LayerScale,
 // +residual) -> LN2 -> fc1 + GELU -> fc2 (+LayerScale, +residual).  `at.lens` (optional) = per-sequence token counts.
 static int run_vit_block(pio_handle c, const VitLayerDev& L, int B, const GemmArgs& g, const VitAttnArgs& at,
@@ -865,6 +916,24 @@ int pio_vit_forward(pio_handle c, const float* imgs, int32_t B, float* tokens, f
   HIP_OK(hipSetDevice(c->cfg.device));
   hipStream_t s = (hipStream_t)stream;
   const int D = c->D, M = B * c->Tp;
+  if (c->vit_f32) {
+    HIP_OK(launch_im2col_f32(imgs, B, c->cfg.crop_dim, c->cfg.patch_size, c->n, c->Kpad, c->f_ape, s));
+    HIP_OK(launch_token_init(c->x, c->cls, c->pos, c->reg, B, c->cfg.num_registers, c->T, c->Tp, D, s));
+    HIP_OK(launch_sgemm_tn(c->f_ape, c->Kpad, c->pe_w32, c->Kpad, c->pe_b, 1.f, c->f_emb, D, B * c->n2, D, c->Kpad, 0, 0, s));
+    HIP_OK(launch_embed_scatter_f32(c->f_emb, c->pos, B, c->n2, c->Tp, c->G, D, c->x, s));
+    if (c->cfg.vit_arch == 1) HIP_OK(launch_layernorm_f32(c->x, c->npre_w, c->npre_b, c->cfg.vit_ln_eps, M, D, c->x, s));
+    for (int l = 0; l < c->cfg.depth; ++l) {
+      const int rc = run_vit_block_f32(c, l, B, (l == c->cfg.depth - 1) ? qkv_last : nullptr, nullptr, s);
+      if (rc != PIO_OK) return rc;
+    }
+    if (c->vhead_w) {
+      HIP_OK(launch_layernorm(c->op, c->x, c->norm_w, c->norm_b, c->cfg.vit_ln_eps, M, D, nullptr, c->tok_tmp, c->T, c->Tp, s));
+      HIP_OK(launch_sgemm_tn(c->tok_tmp, D, c->vhead_w, D, nullptr, 1.f, tokens, c->Dout, B * c->T, c->Dout, D, 0, 0, s));
+    } else {
+      HIP_OK(launch_layernorm(c->op, c->x, c->norm_w, c->norm_b, c->cfg.vit_ln_eps, M, D, nullptr, tokens, c->T, c->Tp, s));
+    }
+    return PIO_OK;
+  }
   HIP_OK(launch_im2col(c->op, imgs, B, c->cfg.crop_dim, c->cfg.patch_size, c->n, c->Kpad, c->ape, s));
   HIP_OK(launch_token_init(c->x, c->cls, c->pos, c->reg, B, c->cfg.num_registers, c->T, c->Tp, D, s));
   GemmArgs g;
@@ -923,7 +992,7 @@ int pio_bbox_double_dino(pio_handle c, const float* tokens, const int32_t* slice
     const int ns = std::min(c->cfg.max_batch, Ns - s0);
     at.B = ns;
     HIP_OK(launch_box_sequences(tokens, slices, s0, ns, NB, c->T, c->Tp, c->G, c->n, D, use_cls, c->x, c->seq_lens, s));
-    const int rc = run_vit_block(c, L, ns, g, at, nullptr, s);
+    const int rc = c->vit_f32 ? run_vit_block_f32(c, c->cfg.depth - 1, ns, nullptr, c->seq_lens, s) : run_vit_block(c, L, ns, g, at, nullptr, s);
     if (rc != PIO_OK) return rc;
     HIP_OK(launch_box_seq_reduce(c->x, c->seq_lens, ns, c->Tp, D, Gs, return_type, out + (size_t)s0 * D, s));
   }

@@ -54,6 +54,14 @@ hipError_t launch_vit_attention(OperandType t, const VitAttnArgs& a, hipStream_t
 // LayerNorm rows of x [M][D] fp32 -> operand type (out16) or fp32 (out32; compacts Tp -> T rows per image)
 hipError_t launch_layernorm(OperandType t, const float* x, const float* w, const float* b, float eps, int M,
                             int D, void* out16, float* out32, int T, int Tp, hipStream_t s);
+// ---- vit_fp32.hip: the exact-fp32 parity mode of the backbone (vit_operand_type = 2); plain kernels
+hipError_t launch_im2col_f32(const float* imgs, int B, int S, int p, int n, int Kpad, float* out, hipStream_t s);
+hipError_t launch_embed_scatter_f32(const float* emb, const float* pos, int B, int n2, int Tp, int G, int D, float* x, hipStream_t s);
+hipError_t launch_attention_f32(const float* qkv, int B, int H, int T, int Tp, int D, float scale, const int32_t* lens, float* out, hipStream_t s);
+hipError_t launch_resid_ls_f32(float* x, const float* y, const float* ls, size_t total, int D, hipStream_t s);
+hipError_t launch_gelu_f32(float* y, size_t n, int act, hipStream_t s);
+hipError_t launch_layernorm_f32(const float* x, const float* w, const float* b, float eps, int M, int D, float* y, hipStream_t s);
+
 // imgs [B][3][S][S] fp32 -> patch rows [B*n2][Kpad] (k = c*p*p + py*p + px; columns >= 3*p*p stay zero)
 hipError_t launch_im2col(OperandType t, const float* imgs, int B, int S, int p, int n, int Kpad, void* out,
                          hipStream_t s);

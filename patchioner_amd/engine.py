@@ -38,7 +38,7 @@ class Engine:
             readout_heads=readout_heads, readout_scale=readout_scale, dec_layers=dec_layers, dec_heads=dec_heads,
             dec_embd=dec_embd, dec_vocab=dec_vocab, dec_positions=dec_positions, prefix_size=prefix_size,
             dec_ln_eps=1e-5, max_batch=max_batch, max_prefixes=max_prefixes, max_steps=max_steps,
-            vit_operand_type={"fp16": 0, "bf16": 1}[vit_dtype], device=device_index,
+            vit_operand_type={"fp16": 0, "bf16": 1, "fp32": 2}[vit_dtype], device=device_index,
             vit_arch={"dinov2": 0, "clip": 1}[vit_arch], vit_out_dim=vit_out_dim)
         self.cfg = cfg
         h = ctypes.c_void_p()

@@ -461,6 +461,51 @@ def test_e2e_forward_vs_reference_fixture(O, golden, with_bank, cfg):
     m.call_log = None
 
 
+@pytest.mark.parametrize("with_bank,cfg", [(True, "decap"), (False, "capdec")])
+def test_e2e_fp32_backbone_mode_is_bit_exact_to_the_reference_fixture(O, golden, with_bank, cfg):
+    """north_star's "greedy ids bit-exact", with NO near-tie clause: in the exact-fp32 backbone mode (vit_dtype="fp32":
+    every ViT GEMM on the fp32 MFMA, fp32 attention / LayerNorm / GELU, csrc/vit_fp32.hip) every caption of the reference's
+    own Patchioner.forward fixture (5 call patterns x 2 configurations: cls, attention-weighted, gaussian boxes with scores,
+    attention-map boxes, controllable sets, traces with and without attention tracing) comes out with the SAME token ids and
+    the same caption strings.  The backbone tokens themselves agree with the fixture's to fp32 round-off."""
+    g = golden("e2e")
+    c = gc.E2E
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    m = _make_model(with_bank, vit_dtype="fp32")
+    imgs = W.synth_images(c["seed_img"], c["B"], c["crop"]).cuda()
+    tokens, _ = m.engine.vit_forward(imgs)
+    np.testing.assert_allclose(tokens[:, 0].cpu().numpy(), g["vit_cls"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(tokens[:, 5::37].cpu().numpy(), g["vit_patch_sample"], rtol=2e-4, atol=2e-5)
+    traces, boxes = gc.e2e_traces(), gc.e2e_boxes()
+    runs = {
+        "_cls_trace": dict(get_cls_capt=True, traces=traces),
+        "_attn_family": dict(get_cls_capt=False, get_avg_self_attn_capt=True, get_avg_patch_capt=True,
+                             gaussian_img_variance=1, traces=traces, use_attention_tracing=True),
+        "_bbox_gauss_scores": dict(get_cls_capt=False, bboxes=boxes.clone(), gaussian_avg=True,
+                                   gaussian_bbox_variance=1.0, compute_scores=True, bs_factor=1),
+        "_bbox_attnmap": dict(get_cls_capt=False, bboxes=boxes.clone(), use_attn_map_for_bboxes=True),
+        "_controllable": dict(get_cls_capt=False, bboxes=boxes.clone(), get_controllable_capts=True, gaussian_avg=True),
+    }
+    n_caps = 0
+    for suffix, kw in runs.items():
+        tag = cfg + suffix
+        m.call_log = []
+        outs = m(imgs.clone(), **kw)
+        ref = meta[tag]
+        G = torch.cat([i for _, i in m.call_log]).cpu().long()
+        P = torch.cat([p for p, _ in m.call_log]).float().cpu()
+        R = torch.cat([torch.as_tensor(g[k]).long().reshape(-1, G.shape[1]) for k in sorted(k for k in g.files if k.startswith(tag + "__ids"))])
+        keep = torch.isfinite(P).all(dim=1)          # a NaN prefix (empty box) decodes garbage in the reference as well
+        assert G.shape == R.shape and torch.equal(G[keep], R[keep]), "%s: ids differ from the reference" % tag
+        n_caps += int(keep.sum())
+        for key in ref:                              # and the strings the caller sees (finite prefixes only: all of them here)
+            if not key.endswith("_scores") and bool(keep.all()):
+                assert outs[key] == ref[key], (tag, key)
+    m.call_log = None
+    print("fp32 backbone mode: %d captions, all ids identical to the reference fixture" % n_caps)
+    assert n_caps >= 20
+
+
 @pytest.mark.parametrize("with_bank", [True, False])
 def test_e2e_full_depth_ids_vs_oracle(O, with_bank):
     """The whole path at FULL backbone depth (12 blocks) on 4 images: cls, attention-weighted and trace captions plus
