@@ -95,7 +95,8 @@ def cpu_baseline():
     imgs = W.synth_images(1, BATCH, CROP)
     rng = np.random.RandomState(2)
     traces = [gc.block_trace(int(rng.randint(0, 13)), int(rng.randint(0, 13))) for _ in range(BATCH)]
-    m.forward(imgs[:2], get_cls_capt=False, traces=traces[:2])      # warm-up (thread pools, allocations)
+    for _ in range(3):                                              # >= 3 warm-up passes: thread pools, allocations
+        m.forward(imgs[:2], get_cls_capt=False, traces=traces[:2])
 
     def timed(fn, n):
         ts = []
@@ -106,20 +107,21 @@ def cpu_baseline():
         return ts
 
     t_all = timed(lambda: m.forward(imgs, get_cls_capt=False, traces=traces), 3)
-    t_c1 = timed(lambda: m.forward(imgs[:4], get_cls_capt=True), 3)
+    t_c1 = timed(lambda: m.forward(imgs[:4], get_cls_capt=True), 10)       # BASELINE config 1: ~0.9 s a step, 10 timed steps
     torch.set_num_threads(1)
     t_one = timed(lambda: m.forward(imgs[:1], get_cls_capt=False, traces=traces[:1]), 1)
     torch.set_num_threads(cores)
     med = sorted(t_all)[1]
     return {"value": BATCH / med, "unit": "captions/s", "cores": cores, "kind": "port",
             "sample": "3 timed steps of the same workload (batch 16, 224^2, 12-layer ViT-B/14, 591753x768 fp32 bank, 30-step "
-                      "cache-less decode) on torch-CPU fp32 after one warm-up: %s s; value = 16 / median"
+                      "cache-less decode) on torch-CPU fp32 after 3 warm-up passes (2 images each): %s s (~2.7 s each: the bounded "
+                      "10-30 s sample); value = 16 / median"
                       % ", ".join("%.1f" % t for t in t_all),
             "samples_s": t_all,
             "one_thread": {"value": 1.0 / t_one[0], "unit": "captions/s", "cores": 1,
                            "sample": "1 step of 1 image / 1 trace (bounded sample), %.1f s" % t_one[0]},
-            "config1_cls_batch4": {"value": 4.0 / sorted(t_c1)[1], "unit": "captions/s", "cores": cores,
-                                   "sample": "BASELINE config 1: 4 x 224^2 images, caption_from=cls, 3 timed steps: %s s"
+            "config1_cls_batch4": {"value": 4.0 / sorted(t_c1)[len(t_c1) // 2], "unit": "captions/s", "cores": cores,
+                                   "sample": "BASELINE config 1: 4 x 224^2 images, caption_from=cls, 10 timed steps after 3 warm-up passes: %s s"
                                              % ", ".join("%.1f" % t for t in t_c1)}}
 
 

@@ -119,6 +119,17 @@ __device__ __forceinline__ float quick_gelu(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// hipFuncSetAttribute (the opt-in above 48 KiB of dynamic LDS) is per DEVICE: one flag per device for the once-only call, so a
+// second engine on another device of the same process gets its own opt-in
+struct DeviceOnce {
+  bool done[64] = {};
+  bool& flag() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return done[dev & 63];
+  }
+};
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

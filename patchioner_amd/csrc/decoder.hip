@@ -730,7 +730,7 @@ static hipError_t dec_gemm_b_launch(const float* W, const float* X, int N, int N
   constexpr int RB = RGB == 4 ? 8 : 12;
   constexpr int ring = RB * 16 * RGB * 64 * 4, tiles = 4 * NCG * RGB * 1024;
   constexpr int smem = ring > tiles ? ring : tiles;
-  static bool attr_set = false;
+  static DeviceOnce attr_once; bool& attr_set = attr_once.flag();
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_dec_gemm_b<RGB, NCG, KS, EPI, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
@@ -1336,7 +1336,7 @@ static hipError_t launch_lmhead_f16(const DecoderArgs& a, hipStream_t s) {
   const int Vp = round_up(a.vocab, 64);
   const int smem = (PIO_LMF16_DEEP != 0 && RG >= 4 ? 4 : 2) * RG * 16 * 64 * 2;
   const int NGp = round_up(ceil_div(a.vocab, 16), 64);
-  static bool attr_set = false;
+  static DeviceOnce attr_once; bool& attr_set = attr_once.flag();
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_lmhead_f16<RG, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? PIO_GEMM_WIDE_OCC
 
 template <typename T, int EPI, int BM, int NBUF>
 static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
-  static bool attr_set = false;
+  static DeviceOnce attr_once; bool& attr_set = attr_once.flag();
   const int stage = (BM + BN) * BK * 2;
   const int smem_bytes = NBUF * stage > 64 * BN * 4 ? NBUF * stage : 64 * BN * 4;
   if (!attr_set) {

@@ -16,24 +16,12 @@
 // columns j * 128 + wc * 32 + [0, 32): quadrant (i, j) needs 64 rows of A-half i and 32 rows of B-half j, so every wave
 // reads every half-tile exactly once per K-tile (fragments stay in registers across the two quadrants that share them).
 //
-// Schedule.  A K-tile is four phases, one quadrant each, in the order (A0,B0) (A0,B1) (A1,B1) (A1,B0); a phase is a LOAD
-// segment (this phase's ds_reads, one half-tile of LDS-DMA for a later K-tile) and a COMPUTE segment (8 MFMAs = 256
-// cycles), each closed by a workgroup barrier.  Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave's
-// COMPUTE segment coincides with its partner's LOAD segment (the matrix pipe sees back-to-back MFMAs while the other
-// wave's LDS reads and DMA issue run beside them).  Segment s: group 0 runs L(p) at s = 2p and C(p) at 2p + 1, group 1
-// L(p) at 2p + 1 and C(p) at 2p + 2.
-//
-// LDS-DMA pipeline (all counts are per wave: 2 buffer_load ... lds instructions per half-tile).  Phase 4t + p issues
-//   p = 0: B1(t+1)   p = 1: A1(t+1)   p = 2: A0(t+2)   p = 3: B0(t+2), then s_waitcnt vmcnt(4)
-// Hazards, by construction (never by "it ran clean"):
-//   WAR  a half-tile last read in phase q (reads retired by the readers' lgkmcnt(0) at the head of C(q), i.e. before the
-//        barrier that ends segment 2q + 2 for the later group) is overwritten by DMA issued in phase >= q + 2 (group 0
-//        issues at segment 2q + 4, group 1 at 2q + 5).  A0, B0 are read in phase 4t and restaged in 4t + 2, 4t + 3;
-//        B1 in 4t + 1 -> 4t + 4; A1 in 4t + 2 -> 4t + 5.
-//   RAW  the vmcnt(4) of phase 4t + 3 retires everything but A0(t+2), B0(t+2), i.e. all of K-tile t + 1; every wave
-//        executes it before the barrier that closes its L segment, and K-tile t + 1 is first read in phase 4t + 4, after
-//        both groups have passed that barrier.  (LDS-DMA data is ordered for a ds_read only by the issuing wave's vmcnt
-//        followed by a barrier the reader has passed.)
+// Schedule (the details, the LDS-DMA pipeline and its WAR / RAW arguments are spelled out at the main loop).  A K-tile is four
+// phases, one quadrant each, in the order (A0,B0) (A0,B1) (A1,B1) (A1,B0); ONE workgroup barrier per phase.  Between two
+// barriers the two wave groups run different programs: waves 0-3 the 8 MFMAs of phase k (operands read in the interval before),
+// then the fragment reads of phase k + 1 and the LDS-DMA issue; waves 4-7 the reads of phase k, the LDS-DMA, then the MFMAs of
+// phase k -- so on every SIMD one wave multiplies while its partner reads.  (Round 2's first schedule, two barriers per phase
+// with the second group one segment behind, measured 1-4 % slower and lives in tools/microbench/attic/ since round 3.)
 #include "common.h"
 #include "kernels.h"
 
@@ -44,9 +32,6 @@ namespace pio {
 #endif
 #ifndef PIO_G256_SETPRIO
 #define PIO_G256_SETPRIO 1
-#endif
-#ifndef PIO_G256_VARIANT        // main-loop schedule the library ships (0 or 1, see the kernel)
-#define PIO_G256_VARIANT 1
 #endif
 
 #ifdef PIO_G256_STAMPS           // diagnostic builds only: s_memtime at kernel entry / first operands landed / main loop done / end,
@@ -96,7 +81,7 @@ template <typename T> struct Vec4h { typedef T type __attribute__((ext_vector_ty
 
 }  // namespace g256
 
-template <typename T, int EPI, int VAR>
+template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void k_vit_gemm256(const GemmArgs g) {
   using namespace g256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -163,98 +148,34 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm256(const GemmArgs g) {
   _Pragma("unroll") for (int s = 0; s < 4; ++s) dst[s] = *(const frag_t*)(smem + half_off(0, (buf), (j)) + b_rd + co[s])
 #define G256_MMA(i, j, fb)                                                                               \
   do {                                                                                                   \
-    if (PIO_G256_SETPRIO && VAR == 0) __builtin_amdgcn_s_setprio(1);                                     \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)      \
         acc[i][j][rt] = SWAP ? mfma32(fb[s], fa[rt][s], acc[i][j][rt]) : mfma32(fa[rt][s], fb[s], acc[i][j][rt]); \
-    if (PIO_G256_SETPRIO && VAR == 0) __builtin_amdgcn_s_setprio(0);                                     \
   } while (0)
 
-  if constexpr (VAR == 0) {
-    // ------------------------------------------------------------------------------------------------------------
-    // schedule 0: two barriers per phase, waves 4-7 one segment behind (file header)
-    // prologue: K-tile 0 whole, A0 / B0 of K-tile 1
-    G256_ISSUE_A(0, 0, 0);
-    G256_ISSUE_W(0, 0, 0);
-    G256_ISSUE_W(0, 1, 0);
-    G256_ISSUE_A(0, 1, 0);
-    G256_ISSUE_A(1, 0, 1);
-    G256_ISSUE_W(1, 0, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    G256_BARRIER();
-    G256_STAMP(1);
-    if (!PIO_G256_NOSTAGGER && wr == 1) G256_BARRIER();        // waves 4-7 run one segment behind
-
-#define G256_KTILE(t, BUF)                                                                               \
-  do {                                                                                                   \
-    /* phase 0: (A0, B0) */                                                                              \
-    G256_READ_A(BUF, 0);                                                                                 \
-    G256_READ_B(fb0, BUF, 0);                                                                            \
-    if ((t) + 1 < nk) G256_ISSUE_W((BUF) ^ 1, 1, (t) + 1);                                               \
-    G256_BARRIER();                                                                                      \
-    G256_MMA(0, 0, fb0);                                                                                 \
-    G256_BARRIER();                                                                                      \
-    /* phase 1: (A0, B1) */                                                                              \
-    G256_READ_B(fb1, BUF, 1);                                                                            \
-    if ((t) + 1 < nk) G256_ISSUE_A((BUF) ^ 1, 1, (t) + 1);                                               \
-    G256_BARRIER();                                                                                      \
-    G256_MMA(0, 1, fb1);                                                                                 \
-    G256_BARRIER();                                                                                      \
-    /* phase 2: (A1, B1) */                                                                              \
-    G256_READ_A(BUF, 1);                                                                                 \
-    if ((t) + 2 < nk) G256_ISSUE_A(BUF, 0, (t) + 2);                                                     \
-    G256_BARRIER();                                                                                      \
-    G256_MMA(1, 1, fb1);                                                                                 \
-    G256_BARRIER();                                                                                      \
-    /* phase 3: (A1, B0) */                                                                              \
-    if ((t) + 2 < nk) {                                                                                  \
-      G256_ISSUE_W(BUF, 0, (t) + 2);                                                                     \
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                   \
-    } else {                                                                                             \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
-    }                                                                                                    \
-    G256_BARRIER();                                                                                      \
-    G256_MMA(1, 0, fb0);                                                                                 \
-    G256_BARRIER();                                                                                      \
-  } while (0)
-#define G256_MAINLOOP(SWAP_)                                                                             \
-  do {                                                                                                   \
-    constexpr bool SWAP = SWAP_;                                                                         \
-    for (int t = 0; t < nk; t += 2) {      /* nk is even (launcher): buffer parity is a literal */       \
-      G256_KTILE(t, 0);                                                                                  \
-      G256_KTILE(t + 1, 1);                                                                              \
-    }                                                                                                    \
-  } while (0)
-
-    if (v_block) G256_MAINLOOP(false);
-    else G256_MAINLOOP(true);
-    if (!PIO_G256_NOSTAGGER && wr == 0) G256_BARRIER();        // re-align: every wave is past its last LDS read
-#undef G256_MAINLOOP
-#undef G256_KTILE
-  } else {
-    // ------------------------------------------------------------------------------------------------------------
-    // schedule 1: ONE barrier per phase, the two groups run DIFFERENT programs between two barriers ("interval" k):
-    //   waves 0-3:  MFMAs of phase k (operands read in interval k-1), then the ds_reads of phase k+1, then the LDS-DMA
-    //   waves 4-7:  the ds_reads of phase k, the LDS-DMA, then the MFMAs of phase k
-    // so one wave of every SIMD multiplies while its partner reads, with half the barriers of schedule 0.
-    // LDS-DMA in interval 4t+0: A1(t+1), 4t+1: A0(t+2), 4t+2: B0(t+2) then s_waitcnt vmcnt(4), 4t+3: B1(t+2).
-    //   WAR  a half-tile read for phase p (by waves 0-3 in interval p-1, by waves 4-7 in interval p; both consumed by
-    //        the MFMAs of interval p, i.e. before the barrier that closes it) is overwritten by DMA issued in an
-    //        interval >= p+1: A0/B0(t) are read for phase 4t and restaged in 4t+1 / 4t+2, B1(t): 4t+1 -> 4t+3,
-    //        A1(t): 4t+2 -> 4t+4.
-    //   RAW  the wait of interval 4t+2 retires all of K-tile t+1 (only A0, B0 of t+2 stay in flight); every wave
-    //        executes it before that interval's barrier, and K-tile t+1 is first read in interval 4t+3 (waves 0-3,
-    //        for phase 4t+4).  K-tile 0: A0, B0, B1 are retired before the loop, A1(0) by an extra wait in interval 0
-    //        (first read in interval 1), so the first MFMA waits for 48 KiB of operands, not for 96.
-    G256_ISSUE_A(0, 0, 0);
-    G256_ISSUE_W(0, 0, 0);
-    G256_ISSUE_W(0, 1, 0);
-    G256_ISSUE_A(0, 1, 0);
-    G256_ISSUE_A(1, 0, 1);
-    G256_ISSUE_W(1, 0, 1);
-    G256_ISSUE_W(1, 1, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // A0, B0, B1 of K-tile 0 have landed
-    G256_BARRIER();
-    G256_STAMP(1);
+  // ------------------------------------------------------------------------------------------------------------
+  // ONE barrier per phase, the two groups run DIFFERENT programs between two barriers ("interval" k):
+  //   waves 0-3:  MFMAs of phase k (operands read in interval k-1), then the ds_reads of phase k+1, then the LDS-DMA
+  //   waves 4-7:  the ds_reads of phase k, the LDS-DMA, then the MFMAs of phase k
+  // so one wave of every SIMD multiplies while its partner reads.
+  // LDS-DMA in interval 4t+0: A1(t+1), 4t+1: A0(t+2), 4t+2: B0(t+2) then s_waitcnt vmcnt(4), 4t+3: B1(t+2).
+  //   WAR  a half-tile read for phase p (by waves 0-3 in interval p-1, by waves 4-7 in interval p; both consumed by
+  //        the MFMAs of interval p, i.e. before the barrier that closes it) is overwritten by DMA issued in an
+  //        interval >= p+1: A0/B0(t) are read for phase 4t and restaged in 4t+1 / 4t+2, B1(t): 4t+1 -> 4t+3,
+  //        A1(t): 4t+2 -> 4t+4.
+  //   RAW  the wait of interval 4t+2 retires all of K-tile t+1 (only A0, B0 of t+2 stay in flight); every wave
+  //        executes it before that interval's barrier, and K-tile t+1 is first read in interval 4t+3 (waves 0-3,
+  //        for phase 4t+4).  K-tile 0: A0, B0, B1 are retired before the loop, A1(0) by an extra wait in interval 0
+  //        (first read in interval 1), so the first MFMA waits for 48 KiB of operands, not for 96.
+  G256_ISSUE_A(0, 0, 0);
+  G256_ISSUE_W(0, 0, 0);
+  G256_ISSUE_W(0, 1, 0);
+  G256_ISSUE_A(0, 1, 0);
+  G256_ISSUE_A(1, 0, 1);
+  G256_ISSUE_W(1, 0, 1);
+  G256_ISSUE_W(1, 1, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // A0, B0, B1 of K-tile 0 have landed
+  G256_BARRIER();
+  G256_STAMP(1);
 
 #define G256_DMA0(t, BUF) if ((t) + 1 < nk) G256_ISSUE_A((BUF) ^ 1, 1, (t) + 1)
 #define G256_DMA1(t, BUF) if ((t) + 2 < nk) G256_ISSUE_A(BUF, 0, (t) + 2)
@@ -262,47 +183,46 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm256(const GemmArgs g) {
 #define G256_DMA3(t, BUF) if ((t) + 2 < nk) G256_ISSUE_W(BUF, 1, (t) + 2)
 #define G256_WAIT2(t)                                                                                    \
   do {                                                                                                   \
-    if ((t) + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                   \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+  if ((t) + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                   \
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
   } while (0)
 #define G256_FIRSTWAIT(t) do { if ((t) == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } while (0)
 #define G256_SB() __builtin_amdgcn_sched_barrier(0)
 
-    // waves 0-3
+  // waves 0-3
 #define G256_KTILE_G0(t, BUF)                                                                     \
   do {                                                                                                   \
-    G256_MMA(0, 0, fb0); G256_SB(); G256_READ_B(fb1, BUF, 1); G256_DMA0(t, BUF); G256_FIRSTWAIT(t); G256_BARRIER(); \
-    G256_MMA(0, 1, fb1); G256_SB(); G256_READ_A(BUF, 1); G256_DMA1(t, BUF); G256_BARRIER();              \
-    G256_MMA(1, 1, fb1); G256_SB(); G256_DMA2(t, BUF); G256_WAIT2(t); G256_BARRIER();                    \
-    G256_MMA(1, 0, fb0); G256_SB();                                                                      \
-    if ((t) + 1 < nk) { G256_READ_A((BUF) ^ 1, 0); G256_READ_B(fb0, (BUF) ^ 1, 0); }                     \
-    G256_DMA3(t, BUF); G256_BARRIER();                                                                   \
+  G256_MMA(0, 0, fb0); G256_SB(); G256_READ_B(fb1, BUF, 1); G256_DMA0(t, BUF); G256_FIRSTWAIT(t); G256_BARRIER(); \
+  G256_MMA(0, 1, fb1); G256_SB(); G256_READ_A(BUF, 1); G256_DMA1(t, BUF); G256_BARRIER();              \
+  G256_MMA(1, 1, fb1); G256_SB(); G256_DMA2(t, BUF); G256_WAIT2(t); G256_BARRIER();                    \
+  G256_MMA(1, 0, fb0); G256_SB();                                                                      \
+  if ((t) + 1 < nk) { G256_READ_A((BUF) ^ 1, 0); G256_READ_B(fb0, (BUF) ^ 1, 0); }                     \
+  G256_DMA3(t, BUF); G256_BARRIER();                                                                   \
   } while (0)
-    // waves 4-7
+  // waves 4-7
 #define G256_KTILE_G1(t, BUF)                                                                     \
   do {                                                                                                   \
-    G256_READ_A(BUF, 0); G256_READ_B(fb0, BUF, 0); G256_DMA0(t, BUF); G256_SB(); G256_MMA(0, 0, fb0); G256_FIRSTWAIT(t); G256_BARRIER(); \
-    G256_READ_B(fb1, BUF, 1); G256_DMA1(t, BUF); G256_SB(); G256_MMA(0, 1, fb1); G256_BARRIER();         \
-    G256_READ_A(BUF, 1); G256_DMA2(t, BUF); G256_SB(); G256_MMA(1, 1, fb1); G256_WAIT2(t); G256_BARRIER(); \
-    G256_DMA3(t, BUF); G256_SB(); G256_MMA(1, 0, fb0); G256_BARRIER();                                   \
+  G256_READ_A(BUF, 0); G256_READ_B(fb0, BUF, 0); G256_DMA0(t, BUF); G256_SB(); G256_MMA(0, 0, fb0); G256_FIRSTWAIT(t); G256_BARRIER(); \
+  G256_READ_B(fb1, BUF, 1); G256_DMA1(t, BUF); G256_SB(); G256_MMA(0, 1, fb1); G256_BARRIER();         \
+  G256_READ_A(BUF, 1); G256_DMA2(t, BUF); G256_SB(); G256_MMA(1, 1, fb1); G256_WAIT2(t); G256_BARRIER(); \
+  G256_DMA3(t, BUF); G256_SB(); G256_MMA(1, 0, fb0); G256_BARRIER();                                   \
   } while (0)
 #define G256_MAINLOOP(SWAP_)                                                                             \
   do {                                                                                                   \
-    constexpr bool SWAP = SWAP_;                                                                         \
-    if (wr == 0) {                                                                                       \
-      G256_READ_A(0, 0); G256_READ_B(fb0, 0, 0);                                                         \
-      for (int t = 0; t < nk; t += 2) { G256_KTILE_G0(t, 0); G256_KTILE_G0(t + 1, 1); }                  \
-    } else {                                                                                             \
-      for (int t = 0; t < nk; t += 2) { G256_KTILE_G1(t, 0); G256_KTILE_G1(t + 1, 1); }                  \
-    }                                                                                                    \
+  constexpr bool SWAP = SWAP_;                                                                         \
+  if (wr == 0) {                                                                                       \
+    G256_READ_A(0, 0); G256_READ_B(fb0, 0, 0);                                                         \
+    for (int t = 0; t < nk; t += 2) { G256_KTILE_G0(t, 0); G256_KTILE_G0(t + 1, 1); }                  \
+  } else {                                                                                             \
+    for (int t = 0; t < nk; t += 2) { G256_KTILE_G1(t, 0); G256_KTILE_G1(t + 1, 1); }                  \
+  }                                                                                                    \
   } while (0)
 
-    if (v_block) G256_MAINLOOP(false);
-    else G256_MAINLOOP(true);
+  if (v_block) G256_MAINLOOP(false);
+  else G256_MAINLOOP(true);
 #undef G256_MAINLOOP
 #undef G256_KTILE_G0
 #undef G256_KTILE_G1
-  }
 #undef G256_READ_A
 #undef G256_READ_B
 #undef G256_MMA
@@ -497,27 +417,27 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm256(const GemmArgs g) {
   G256_STAMP(3);
 }
 
-template <typename T, int EPI, int VAR>
+template <typename T, int EPI>
 static hipError_t launch256_one(const GemmArgs& a, hipStream_t s) {
-  static bool attr_set = false;
+  static DeviceOnce attr_once; bool& attr_set = attr_once.flag();
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_vit_gemm256<T, EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)k_vit_gemm256<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        g256::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int grid = ceil_div(a.M, g256::TM) * (a.N / g256::TN);
-  hipLaunchKernelGGL((k_vit_gemm256<T, EPI, VAR>), dim3(grid), dim3(512), g256::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((k_vit_gemm256<T, EPI>), dim3(grid), dim3(512), g256::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
-template <typename T, int VAR>
+template <typename T>
 static hipError_t launch256_typed(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   switch (epi) {
-    case EPI_PATCH_EMBED: return launch256_one<T, EPI_PATCH_EMBED, VAR>(a, s);
-    case EPI_QKV: return launch256_one<T, EPI_QKV, VAR>(a, s);
-    case EPI_RESIDUAL: return launch256_one<T, EPI_RESIDUAL, VAR>(a, s);
-    case EPI_GELU: return launch256_one<T, EPI_GELU, VAR>(a, s);
+    case EPI_PATCH_EMBED: return launch256_one<T, EPI_PATCH_EMBED>(a, s);
+    case EPI_QKV: return launch256_one<T, EPI_QKV>(a, s);
+    case EPI_RESIDUAL: return launch256_one<T, EPI_RESIDUAL>(a, s);
+    case EPI_GELU: return launch256_one<T, EPI_GELU>(a, s);
   }
   return hipErrorInvalidValue;
 }
@@ -531,15 +451,8 @@ bool vit_gemm256_fits(GemmEpilogue epi, const GemmArgs& a) {
 
 hipError_t launch_vit_gemm256(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || !vit_gemm256_fits(epi, a)) return hipErrorInvalidValue;
-  return t == OP_F16 ? launch256_typed<f16, PIO_G256_VARIANT>(epi, a, s) : launch256_typed<bf16, PIO_G256_VARIANT>(epi, a, s);
+  return t == OP_F16 ? launch256_typed<f16>(epi, a, s) : launch256_typed<bf16>(epi, a, s);
 }
 
-#ifdef PIO_G256_ALL_VARIANTS    // diagnostic builds (tools/microbench/gemm256_bench.hip): every schedule in one binary
-hipError_t launch_vit_gemm256_variant(int var, OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
-  if (a.M <= 0 || !vit_gemm256_fits(epi, a)) return hipErrorInvalidValue;
-  if (var == 0) return t == OP_F16 ? launch256_typed<f16, 0>(epi, a, s) : launch256_typed<bf16, 0>(epi, a, s);
-  return t == OP_F16 ? launch256_typed<f16, 1>(epi, a, s) : launch256_typed<bf16, 1>(epi, a, s);
-}
-#endif
 
 }  // namespace pio

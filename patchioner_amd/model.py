@@ -84,7 +84,7 @@ class Patchioner(nn.Module):
                  talk2dino_attn_type='qkv', calculate_argmax_text=False, online_texts=None, clip_model_name=None,
                  use_open_clip=False, viecap_config=None, regionclip_config=None, invite_config=None,
                  denseclip_config=None, alphaclip_config=None, clipcap_config=None, hf_repo_id=None,
-                 dino_weights=None, memory_bank=None, synthetic_seed=None, max_batch=16, max_prefixes=64,
+                 dino_weights=None, memory_bank=None, synthetic_seed=None, max_batch=16, max_prefixes=128,
                  vit_dtype="fp16", memory_bank_texts=None, **kwargs):
         super().__init__(**kwargs)
         given = dict(proxyclip_clipmodel=proxyclip_clipmodel,
@@ -295,7 +295,7 @@ class Patchioner(nn.Module):
             memory_bank_texts=config.get('memory_bank_texts', None),
             synthetic_seed=config.get('synthetic_seed', None),
             max_batch=config.get('max_batch', 16),
-            max_prefixes=config.get('max_prefixes', 64),
+            max_prefixes=config.get('max_prefixes', 128),       # what ONE greedy decode serves (the engine's limit)
             vit_dtype=config.get('vit_dtype', 'fp16'),
         )
         model.to(device)

@@ -58,8 +58,43 @@ static pio_handle make(bool viecap) {
   return h;
 }
 
+// The CLIP ViT variant (vit_arch 1: no registers, native grid, norm_pre, bias-free patch conv, no LayerScale, head) in the
+// exact-fp32 parity mode (vit_operand_type 2: fp32 weight copies and workspaces): load, finalize, forward, misuse, destroy.
+static void clip_fp32_round() {
+  pio_config c;
+  memset(&c, 0, sizeof(c));
+  c.embed_dim = 64; c.depth = 1; c.num_heads = 1; c.patch_size = 16; c.num_registers = 0; c.pretrain_grid = 2; c.crop_dim = 32;
+  c.vit_ln_eps = 1e-5f; c.readout_heads = 1; c.readout_scale = 0.125f; c.dec_layers = 1; c.dec_heads = 4; c.dec_embd = 768;
+  c.dec_vocab = 64; c.dec_positions = 160; c.prefix_size = 32; c.dec_ln_eps = 1e-5f; c.max_batch = 2; c.max_prefixes = 4;
+  c.max_steps = 30; c.vit_operand_type = 2; c.device = 0; c.vit_arch = 1; c.vit_out_dim = 32;
+  pio_handle bad = nullptr;
+  pio_config w = c;
+  w.num_registers = 4;
+  EXPECT_FAIL(pio_create(&w, &bad));                                   // the CLIP ViT has no registers
+  w = c; w.vit_arch = 0;
+  EXPECT_FAIL(pio_create(&w, &bad));                                   // a head width other than embed_dim needs vit_arch 1
+  pio_handle h = nullptr;
+  CK(pio_create(&c, &h));
+  const int64_t D = 64;
+  load(h, "cls_token", {1, 1, D}); load(h, "pos_embed", {1, 5, D}); load(h, "patch_embed.proj.weight", {D, 3, 16, 16});
+  load(h, "norm.weight", {D}); load(h, "norm.bias", {D}); load(h, "norm_pre.weight", {D}); load(h, "norm_pre.bias", {D});
+  load(h, "head.weight", {32, D});
+  const char* b = "blocks.0.";
+  for (const char* k : {"norm1.weight", "norm1.bias", "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc2.bias"}) load(h, std::string(b) + k, {D});
+  load(h, std::string(b) + "attn.qkv.bias", {3 * D}); load(h, std::string(b) + "mlp.fc1.bias", {4 * D});
+  load(h, std::string(b) + "attn.qkv.weight", {3 * D, D}); load(h, std::string(b) + "attn.proj.weight", {D, D});
+  load(h, std::string(b) + "mlp.fc1.weight", {4 * D, D}); load(h, std::string(b) + "mlp.fc2.weight", {D, 4 * D});
+  CK(pio_finalize_weights(h));
+  std::vector<float> imgs(2 * 3 * 32 * 32, 0.1f), tok(2 * 5 * 32), qkv(2 * 5 * 192), sa(2 * 4);
+  CK(pio_vit_forward(h, imgs.data(), 2, tok.data(), nullptr, nullptr));
+  EXPECT_FAIL(pio_vit_forward(h, imgs.data(), 2, tok.data(), qkv.data(), nullptr));          // no qkv capture on this backbone
+  EXPECT_FAIL(pio_cls_attention(h, qkv.data(), tok.data(), 2, sa.data(), nullptr, nullptr, nullptr, nullptr));
+  CK(pio_destroy(h));
+}
+
 int main() {
   for (int it = 0; it < 12; ++it) {
+    if (it < 3) clip_fp32_round();
     pio_handle h = make(false);
     std::vector<float> bank(16 * 384, 0.5f);
     for (int d = 0; d < 384; ++d) bank[5 * 384 + d] = 0.f;             // one zero row: dropped at load

@@ -47,6 +47,12 @@ hipError_t launch_vit_gemm(OperandType, GemmEpilogue, const GemmArgs&, hipStream
 hipError_t launch_vit_attention(OperandType, const VitAttnArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_layernorm(OperandType, const float*, const float*, const float*, float, int, int, void*, float*, int, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_im2col(OperandType, const float*, int, int, int, int, int, void*, hipStream_t) { return hipSuccess; }
+hipError_t launch_im2col_f32(const float*, int, int, int, int, int, float*, hipStream_t) { return hipSuccess; }
+hipError_t launch_embed_scatter_f32(const float*, const float*, int, int, int, int, int, float*, hipStream_t) { return hipSuccess; }
+hipError_t launch_attention_f32(const float*, int, int, int, int, int, float, const int32_t*, float*, hipStream_t) { return hipSuccess; }
+hipError_t launch_resid_ls_f32(float*, const float*, const float*, size_t, int, hipStream_t) { return hipSuccess; }
+hipError_t launch_gelu_f32(float*, size_t, int, hipStream_t) { return hipSuccess; }
+hipError_t launch_layernorm_f32(const float*, const float*, const float*, float, int, int, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_box_sequences(const float*, const int32_t*, int, int, int, int, int, int, int, int, int, float*, int32_t*, hipStream_t) { return hipSuccess; }
 hipError_t launch_box_seq_reduce(const float*, const int32_t*, int, int, int, int, int, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_token_init(float*, const float*, const float*, const float*, int, int, int, int, int, hipStream_t) { return hipSuccess; }

@@ -179,7 +179,7 @@ def test_bbox_center_pick_golden(golden):
     eng = Engine(embed_dim=768, depth=1, num_heads=12, num_registers=4, crop_dim=224, max_batch=4)
     try:
         m = Shim()
-        m.engine, m.patch_size, m.embed_dim = eng, 14, 768
+        m.engine, m.patch_size, m.embed_dim, m.token_dim = eng, 14, 768, 768
         m._center_choices = lambda b, s: Patchioner._center_choices(m, b, s)
         tokens = _tokens_from_patches(eng, gc.box_patches())
         out = Patchioner._bbox_feats(m, tokens, gc.boxes_odd_spans(), True, 0, False, None)
@@ -263,11 +263,11 @@ def test_projection_full_bank_properties(O):
 
 
 @pytest.mark.parametrize("D,M", [(768, 100003), (768, 2049), (768, 31), (384, 40000), (512, 20011)])
-def test_projection_round2_kernel_is_bit_identical_to_round1(D, M):
-    """k_project2 (two LDS-DMA tile buffers, GEMM2(t) and GEMM1(t+1) back to back, two barriers per tile) performs the
-    arithmetic of k_project in the same order: same bits, for 16- and 32-query passes, ragged query counts, banks that end
-    inside a tile / a slab / hold fewer rows than there are workgroups, zero rows (dropped at load), every bank width."""
-    import os
+def test_projection_ragged_shapes_vs_oracle(O, D, M):
+    """k_project2 against the oracle's line-by-line restatement of Im2TxtProjector.project (im2txtprojection.py:367-385) at the
+    awkward shapes: 16- and 32-query passes, ragged query counts, banks that end inside a tile / a slab / hold fewer rows than
+    there are workgroups, a zero row (dropped at load), every bank width; and the same bits when a call is repeated.  (Rounds
+    1-2 held this kernel bit-identical to round 1's k_project on these shapes; that kernel now lives in tools/microbench/attic.)"""
     from patchioner_amd.engine import Engine
     dims = {768: (768, 12), 384: (384, 6), 512: (768, 12)}[D]
     e = Engine(embed_dim=dims[0], depth=1, num_heads=dims[1], num_registers=4, crop_dim=224, max_batch=1, max_prefixes=128)
@@ -278,18 +278,13 @@ def test_projection_round2_kernel_is_bit_identical_to_round1(D, M):
         if M > 100:
             bank[5] = 0
         e.set_memory_bank(bank)
+        kept = bank[bank.norm(dim=-1) != 0]
         for N in (1, 16, 17, 32, 47, 128):
             q = torch.randn(N, D, generator=g)
-            os.environ.pop("PIO_PROJECT_V1", None)
-            new, nb = e.project(dev(q), normalize=True, n_best=3)
-            os.environ["PIO_PROJECT_V1"] = "1"
-            try:
-                old, ob = e.project(dev(q), normalize=True, n_best=3)
-            finally:
-                os.environ.pop("PIO_PROJECT_V1", None)
-            assert torch.equal(new, old), (D, M, N, float((new - old).abs().max()))
-            assert torch.equal(nb, ob)
-            assert bool(torch.isfinite(new).all())
+            got = e.project(dev(q), normalize=True)
+            again = e.project(dev(q), normalize=True)
+            assert torch.equal(got, again) and bool(torch.isfinite(got).all())
+            close(got, O.project(q.clone(), kept, normalize=True), rtol=2e-4, atol=5e-6)
     finally:
         e.close()
 

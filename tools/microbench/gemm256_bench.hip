@@ -3,7 +3,6 @@
 //   gemm256_bench [check|time|both] [B ...]
 // check: every output buffer of the new kernel compared bit for bit with the old kernel's (all epilogues, fp16 and bf16,
 //        with and without the fp32 qkv capture, a ragged last tile);  time: interleaved rounds, random operands.
-#define PIO_G256_ALL_VARIANTS 1
 #define PIO_G256_STAMPS 1
 #define PIO_ROLL_STAMPS 1
 #include "../../patchioner_amd/csrc/vit_gemm.hip"
@@ -99,11 +98,11 @@ static void reset_outputs(const Bufs& b) {
   fill32(b.x, b.sz_x / 4, 1.0f, 0.f, 9);
 }
 
-static const int NVAR = 3;      // candidates beside the 128-tile kernel: 256 kernel schedule 0, schedule 1, the rolling persistent kernel
+static const int NVAR = 2;      // candidates beside the 128-tile kernel: the 256 kernel, the rolling persistent kernel
 static hipError_t launch_candidate(int var, OperandType op, GemmEpilogue e, const GemmArgs& g) {
-  return var == 2 ? launch_vit_gemm_roll(op, e, g, 0) : launch_vit_gemm256_variant(var, op, e, g, 0);
+  return var == 1 ? launch_vit_gemm_roll(op, e, g, 0) : launch_vit_gemm256(op, e, g, 0);
 }
-static bool candidate_fits(int var, GemmEpilogue e, const GemmArgs& g) { return var == 2 ? vit_gemm_roll_fits(e, g) : vit_gemm256_fits(e, g); }
+static bool candidate_fits(int var, GemmEpilogue e, const GemmArgs& g) { return var == 1 ? vit_gemm_roll_fits(e, g) : vit_gemm256_fits(e, g); }
 static int check(int B, int side, int D, bool bf) {
   Bufs b = make(B, side, D, bf);
   const OperandType op = bf ? OP_BF16 : OP_F16;
@@ -141,8 +140,8 @@ static void time_all(int B, int side, int D) {
   CK(hipMemset(b.ls, 0, D * 4));              // x stays bounded over repeated residual launches
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int rounds = 7, it = 10;
-  printf("B=%d (M=%d), D=%d, T=%d      median us (TFLOP/s): old 128-tile kernel | 256 kernel, schedule 0 | schedule 1 | rolling\n", B, b.M, D, b.T);
-  double tot[1 + NVAR] = {0, 0, 0, 0}, totfl = 0;
+  printf("B=%d (M=%d), D=%d, T=%d      median us (TFLOP/s): old 128-tile kernel | 256 kernel | rolling\n", B, b.M, D, b.T);
+  double tot[1 + NVAR] = {0, 0, 0}, totfl = 0;
   for (const Case& c : CASES) {
     GemmArgs g = args_for(b, c);
     std::vector<float> tt[1 + NVAR];
@@ -162,7 +161,7 @@ static void time_all(int B, int side, int D) {
     printf("  %s %6dx%4dx%4d ", c.name, g.M, g.N, g.K);
     const int mult = c.which <= 3 ? 12 : (c.which == 4 ? 1 : 0);   // launches per 12-block forward (11 + 1 qkv with capture ignored)
     for (int which = 0; which < 1 + NVAR; ++which) {
-      if (tt[which].empty()) { printf(" |      -        "); if (which == NVAR && !tt[2].empty()) tot[which] += mult * tt[2][tt[2].size() / 2]; continue; }
+      if (tt[which].empty()) { printf(" |      -        "); if (which == NVAR && !tt[1].empty()) tot[which] += mult * tt[1][tt[1].size() / 2]; continue; }
       std::sort(tt[which].begin(), tt[which].end());
       const double us = tt[which][tt[which].size() / 2];
       printf(" | %7.1f (%5.0f)", us, fl / us / 1e6);
@@ -185,15 +184,15 @@ static void stamps(int B, int side, int D) {
   unsigned long long* dbuf; CK(hipMalloc(&dbuf, maxwg * 4 * 8));
   std::vector<unsigned long long> h(maxwg * 4);
   printf("stamps B=%d: mean shader-clock cycles per workgroup (100 MHz s_memtime ticks x clock ratio not applied: raw s_memtime units)\n", B);
-  for (int var = 0; var < 2; ++var)
+  for (int var = 0; var < 1; ++var)
     for (const Case& c : CASES) {
       GemmArgs g = args_for(b, c);
       if (!vit_gemm256_fits(c.e, g)) continue;
       const int nwg = ceil_div(g.M, 256) * (g.N / 256);
-      for (int i = 0; i < 3; ++i) CK(launch_vit_gemm256_variant(var, OP_F16, c.e, g, 0));
+      for (int i = 0; i < 3; ++i) CK(launch_vit_gemm256(OP_F16, c.e, g, 0));
       CK(hipMemset(dbuf, 0, maxwg * 4 * 8));
       CK(hipMemcpyToSymbol(HIP_SYMBOL(g256_stamps), &dbuf, sizeof(dbuf)));
-      CK(launch_vit_gemm256_variant(var, OP_F16, c.e, g, 0));
+      CK(launch_vit_gemm256(OP_F16, c.e, g, 0));
       CK(hipDeviceSynchronize());
       unsigned long long* nul = nullptr;
       CK(hipMemcpyToSymbol(HIP_SYMBOL(g256_stamps), &nul, sizeof(nul)));
@@ -203,7 +202,7 @@ static void stamps(int B, int side, int D) {
         pro += (double)(h[4 * w + 1] - h[4 * w]); mainl += (double)(h[4 * w + 2] - h[4 * w + 1]); epi += (double)(h[4 * w + 3] - h[4 * w + 2]);
         first = std::min(first, h[4 * w]); last = std::max(last, h[4 * w + 3]);
       }
-      printf("  schedule %d %s %4d WGs: prologue %8.0f  main loop %8.0f (%2d K-tiles: %6.0f per K-tile)  epilogue %8.0f  | kernel span %8llu\n", var,
+      printf("  256 kernel (%d) %s %4d WGs: prologue %8.0f  main loop %8.0f (%2d K-tiles: %6.0f per K-tile)  epilogue %8.0f  | kernel span %8llu\n", var,
              c.name, nwg, pro / nwg, mainl / nwg, g.K / 64, mainl / nwg / (g.K / 64), epi / nwg, last - first);
     }
   CK(hipFree(dbuf));
