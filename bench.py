@@ -29,7 +29,7 @@ BATCH = 16
 CROP = 224
 BANK_ROWS = 591753
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
-GEMM_KERNEL = "k_vit_gemm256 / k_vit_gemm"    # 256 x 256 tiles from 144 tiles per GEMM on, 128-row tiles below (vit_gemm.hip)
+GEMM_KERNEL = "k_vit_gemm_roll / k_vit_gemm256 / k_vit_gemm"    # persistent rolling-epilogue kernel for qkv / fc1 from 704 tiles on, 256 x 256 tiles from 144, 128-row tiles below (vit_gemm.hip)
 HBM_PEAK_GBS = 8000.0
 
 

@@ -49,6 +49,9 @@
 
 namespace pio {
 
+#ifndef PIO_ATTN_PLAIN_VALU   // 1: the softmax's FMAs / adds as plain VALU instructions (see the kernel)
+#define PIO_ATTN_PLAIN_VALU 1
+#endif
 #ifndef PIO_ATTN_OCC          // waves per SIMD k_vit_attention is compiled for: 2 (144 VGPRs, three workgroups per CU in practice);
 #define PIO_ATTN_OCC 2         // 4 = 128 VGPRs with 56 B of scratch, measured: see the file header
 #endif
@@ -209,6 +212,29 @@ __global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAt
           }
         m_run = m_new;
       }
+#if PIO_ATTN_PLAIN_VALU
+      // plain (un-packed) fp32 VALU: v_pk_fma_f32 / v_pk_add_f32 do not run beside another wave's MFMAs on gfx950, plain
+      // v_fma_f32 / v_add_f32 do (tools/microbench/mfma_valu_overlap2.hip), and three waves share a SIMD here
+      float rs_a = 0.f, rs_b = 0.f;
+      typedef typename Vec2<T>::type half2_t;
+      half2_t ph[2][8];
+      const float nm = -m_run;
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          float z0, z1;
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(z0) : "v"(st[kbk][r]), "v"(sl2), "v"(nm));
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(z1) : "v"(st[kbk][r + 1]), "v"(sl2), "v"(nm));
+          f32x2 p;
+          p[0] = __builtin_amdgcn_exp2f(z0);
+          p[1] = __builtin_amdgcn_exp2f(z1);
+          asm("v_add_f32 %0, %0, %1" : "+v"(rs_a) : "v"(p[0]));
+          asm("v_add_f32 %0, %0, %1" : "+v"(rs_b) : "v"(p[1]));
+          ph[kbk][r >> 1] = __builtin_convertvector(p, half2_t);
+        }
+      const f32x2 rs2 = {rs_a, rs_b};
+#else
       const f32x2 sl2v = {sl2, sl2}, mv = {m_run, m_run};
       f32x2 rs2 = {0.f, 0.f};
       typedef typename Vec2<T>::type half2_t;
@@ -225,6 +251,7 @@ __global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAt
           rs2 += p;
           ph[kbk][r >> 1] = __builtin_convertvector(p, half2_t);
         }
+#endif
       float rs = rs2[0] + rs2[1];
       rs = xor32_add(rs);
       l_run += rs;

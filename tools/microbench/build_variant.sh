@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../.."
 name=$1; shift
 out=tools/microbench/bin/var_$name; mkdir -p $out
-for s in api.cpp vit_gemm.hip vit_gemm256.hip vit_attention.hip vit_misc.hip region.hip project.hip decoder.hip viecap.hip preprocess.hip; do
+for s in api.cpp vit_gemm.hip vit_gemm256.hip vit_gemm_roll.hip vit_attention.hip vit_fp32.hip vit_misc.hip region.hip project.hip decoder.hip viecap.hip preprocess.hip; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -w -I include -I patchioner_amd/csrc "$@" -c patchioner_amd/csrc/$s -o $out/${s%.*}.o &
 done
 wait
