@@ -90,16 +90,31 @@ def all_gather_equal_ids(ids: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
+def _id_columns(model) -> int:
+    """Columns of the id tensor a caption call of ``model`` produces on EVERY rank (also on one whose shard is empty): 30 greedy
+    steps for the DeCap / CapDec decoder (decap.py:116), 64 for the ViECap greedy search (search.py:108-191)."""
+    if getattr(model, "calculate_argmax_text", False):
+        raise ValueError("sharded captioning gathers token ids; a calculate_argmax_text model returns bank texts and has none")
+    return 64 if getattr(model, "viecap", None) is not None else 30
+
+
+def _last_ids(model, steps: int) -> torch.Tensor:
+    ids = model.last_ids
+    if ids is None or ids.dim() != 2 or ids.shape[1] != steps:
+        raise RuntimeError("the model's last caption call left no [N, %d] id tensor to gather" % steps)
+    return ids
+
+
 def sharded_trace_captions(model, imgs: torch.Tensor, traces: Sequence, detokenize, group=None, **fwd) -> List[str]:
     """Caption a global batch: every rank receives the same (imgs, traces), processes its contiguous shard
     with `model(...)` and all ranks return the captions of the whole batch in the original order."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     s, e = shard_bounds(imgs.shape[0], world, rank)
-    steps = 30
+    steps = _id_columns(model)
     if e > s:
         model(imgs[s:e], get_cls_capt=False, traces=list(traces[s:e]), **fwd)
-        ids = model.last_ids
+        ids = _last_ids(model, steps)
     else:
         ids = torch.zeros(0, steps, dtype=torch.int32, device=imgs.device)
     all_ids = all_gather_ids(ids, group)
@@ -116,10 +131,10 @@ def sharded_box_captions(model, imgs: torch.Tensor, bboxes: torch.Tensor, detoke
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     B, NB = bboxes.shape[0], bboxes.shape[1]
     s, e = shard_bounds(B, world, rank)
-    steps = 30
+    steps = _id_columns(model)
     if e > s:
         model(imgs[s:e], get_cls_capt=False, bboxes=bboxes[s:e], **fwd)       # a view: the in-place // patch_size reaches the caller
-        ids = model.last_ids
+        ids = _last_ids(model, steps)
     else:
         ids = torch.zeros(0, steps, dtype=torch.int32, device=imgs.device)
     flat = detokenize(all_gather_ids(ids, group).cpu().tolist())

@@ -617,7 +617,9 @@ class Patchioner(nn.Module):
         if self.viecap is not None:
             if return_n_best_sims:
                 raise Exception("return_n_best_sims is not supported with viecap")
-            return self.viecap.forward(dino_tokens, compute_scores=compute_scores)
+            out = self.viecap.forward(dino_tokens, compute_scores=compute_scores)
+            self.last_ids = self.viecap.last_ids      # [N, 64] ids of the greedy search: what dist.sharded_* gathers
+            return out
         if self.im_proj is None:
             project = False
         x = dino_tokens
@@ -625,6 +627,7 @@ class Patchioner(nn.Module):
             x = torch.tensor(x, dtype=torch.float)
         xd = x.to(device=eng.device, dtype=torch.float32).contiguous()
         if self.calculate_argmax_text:
+            self.last_ids = None                       # no decoder on this path: nothing for dist.sharded_* to gather
             # model.py:1408-1411 -> im2txtprojection.py:367-375: the text of the most similar bank row, no decoder.  The row
             # index counts the rows kept at load while the texts are the file's unfiltered list (the reference's indexing).
             sims, rows = eng.topk_rows(xd, k=int(return_n_best_sims) if return_n_best_sims else 1)

@@ -132,25 +132,70 @@ DEFAULTS = {  # VieCap.defaults (entrypoint.py:61-80)
 }
 
 
+# name_of_entities_text -> (vocabulary file, its reader, stem of the pickled [K, C] embeddings)  (entrypoint.py:186-219;
+# readers: load_annotations.py:78-150).  Every reader lower-cases / strips, optionally keeps single words only, and sorts.
+def _read_vg(path):
+    with open(path, "rb") as f:
+        return list(pickle.load(f)["objects"]["joint"])
+
+
+def _read_json_list(path):
+    with open(path) as f:
+        return list(json.load(f))
+
+
+def _read_open_images(path):
+    import csv
+    with open(path, newline="") as f:
+        rows = list(csv.DictReader(f))
+    out = []
+    for r in rows:                                   # load_annotations.py:110-115: "Bat (Animal)" -> "bat"
+        e = r["DisplayName"].lower().strip()
+        if e[-1] == ")":
+            e = e[:e.find("(")].strip()
+        out.append(e)
+    return out
+
+
+def _read_vinvl_vg(path):
+    with open(path) as f:
+        return list(json.load(f)["object_count"])
+
+
+_VOCABULARIES = {
+    "visual_genome_entities": ("all_objects_attributes_relationships.pickle", _read_vg, "visual_genome_embedding"),
+    "coco_entities": ("coco_categories.json", _read_json_list, "coco_embeddings"),
+    "open_image_entities": ("oidv7-class-descriptions-boxable.csv", _read_open_images, "open_image_embeddings"),
+    "vinvl_vg_entities": ("VG-SGG-dicts-vgoi6-clipped.json", _read_vinvl_vg, "vg_embeddings"),
+    "vinvl_vgoi_entities": ("vgcocooiobjects_v1_class2ind.json", _read_json_list, "vgoi_embeddings"),   # dict {name: index}: its keys
+}
+
+
 def _entity_files(args: Namespace, suffix: str):
-    """get_viecap_texts_embeddings (entrypoint.py:174-223) for the vocabularies kept as a plain list + a pickled tensor."""
+    """get_viecap_texts_embeddings (entrypoint.py:179-223): the entity names of the selected vocabulary (default
+    ``vinvl_vgoi_entities``) and their pickled text embeddings ``<stem>_<suffix>[_with_ensemble].pickle``.  The directory is
+    ``files_path/annotations/vocabulary`` or, when that is missing, the ``vocabulary`` directory next to this file (the
+    reference's fallback, entrypoint.py:183-185).  The embeddings must exist: computing them needs the CLIP text tower."""
     suffix = suffix.replace("/", "")
     vocab_dir = os.path.join(args.files_path, "annotations/vocabulary")
     if not os.path.exists(vocab_dir):
-        raise FileNotFoundError("entity vocabulary directory %r not found (pass viecap.entities_text / viecap.texts_embeddings "
-                                "or point viecap.files_path at the reference's files)" % vocab_dir)
-    if args.name_of_entities_text != "coco_entities":
-        raise NotImplementedError("entity vocabulary %r: only 'coco_entities' (a JSON list + a pickled [K, C] tensor) is read "
-                                  "from files; pass viecap.entities_text / viecap.texts_embeddings for the others" % args.name_of_entities_text)
-    with open(os.path.join(vocab_dir, "coco_categories.json")) as f:
-        ents = json.load(f)
-    if not args.disable_all_entities:
-        ents = [e.lower().strip() for e in ents]
-    else:
-        ents = [e.lower().strip() for e in ents if len(e.split()) == 1]
+        vocab_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vocabulary")
+    if not os.path.exists(vocab_dir):
+        raise FileNotFoundError("entity vocabulary directory not found under %r nor next to viecap.py (pass viecap.entities_text / "
+                                "viecap.texts_embeddings or point viecap.files_path at the reference's files)" % args.files_path)
+    if args.name_of_entities_text not in _VOCABULARIES:
+        raise ValueError("The entities text should be input correctly! (%r)" % (args.name_of_entities_text,))      # entrypoint.py:220-222
+    fname, reader, stem = _VOCABULARIES[args.name_of_entities_text]
+    ents = [e.lower().strip() for e in reader(os.path.join(vocab_dir, fname))]
+    if args.disable_all_entities:
+        ents = [e for e in ents if len(e.split()) == 1]
     ents.sort()
-    name = "coco_embeddings_%s%s.pickle" % (suffix, "_with_ensemble" if args.prompt_ensemble else "")
-    with open(os.path.join(vocab_dir, name), "rb") as f:
+    name = "%s_%s%s.pickle" % (stem, suffix, "_with_ensemble" if args.prompt_ensemble else "")
+    path = os.path.join(vocab_dir, name)
+    if not os.path.exists(path):
+        raise FileNotFoundError("%r not found: the entity text embeddings are computed with the CLIP text tower (out of scope "
+                                "here); provide the pickle or pass viecap.texts_embeddings" % path)
+    with open(path, "rb") as f:
         emb = pickle.load(f)
     return ents, torch.as_tensor(emb).float()
 

@@ -83,3 +83,60 @@ def test_config_errors_are_loud(case):
         V.VieCapHead({k: v for k, v in base.items() if k != "tokenizer"}, FakeEngine(), "ViT-B/16")
     with pytest.raises(ValueError):
         V.VieCapHead(dict(base, texts_embeddings=emb[:, :512]), FakeEngine(), "ViT-B/16")
+
+
+def test_entity_vocabularies_default_vinvl_vgoi_and_the_others(tmp_path):
+    """get_viecap_texts_embeddings (P/src/viecap/entrypoint.py:179-223): every vocabulary the reference reads, starting with its
+    DEFAULT ``vinvl_vgoi_entities`` (a {name: index} json + vgoi_embeddings_<suffix>.pickle); names lower-cased, stripped,
+    sorted, single words only with disable_all_entities; a missing embeddings pickle or an unknown name fails loudly."""
+    import csv
+    import json
+    import pickle
+    from argparse import Namespace
+    import pytest
+    import torch
+    from patchioner_amd.viecap import _entity_files
+    vd = tmp_path / "annotations" / "vocabulary"
+    vd.mkdir(parents=True)
+    json.dump({"Traffic Light": 0, " zebra": 1, "apple": 2}, open(vd / "vgcocooiobjects_v1_class2ind.json", "w"))
+    json.dump(["Dog", "hot dog", "cat "], open(vd / "coco_categories.json", "w"))
+    json.dump({"object_count": {"Tree": 5, "street sign": 2}}, open(vd / "VG-SGG-dicts-vgoi6-clipped.json", "w"))
+    pickle.dump({"objects": {"joint": {"Lamp", "tea pot"}}}, open(vd / "all_objects_attributes_relationships.pickle", "wb"))
+    with open(vd / "oidv7-class-descriptions-boxable.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["LabelName", "DisplayName"])
+        w.writerow(["/m/1", "Bat (Animal)"])
+        w.writerow(["/m/2", "Ball"])
+    for stem, k in (("vgoi_embeddings", 3), ("coco_embeddings", 3), ("vg_embeddings", 2), ("visual_genome_embedding", 2), ("open_image_embeddings", 2)):
+        pickle.dump(torch.arange(k * 4, dtype=torch.float32).view(k, 4), open(vd / ("%s_ViT-B16.pickle" % stem), "wb"))
+    pickle.dump(torch.ones(3, 4), open(vd / "vgoi_embeddings_ViT-B16_with_ensemble.pickle", "wb"))
+
+    def args(name, **kw):
+        return Namespace(files_path=str(tmp_path), name_of_entities_text=name, disable_all_entities=False, prompt_ensemble=False, **kw)
+    ents, emb = _entity_files(args("vinvl_vgoi_entities"), "ViT-B/16")
+    assert ents == ["apple", "traffic light", "zebra"] and emb.shape == (3, 4)
+    a = args("vinvl_vgoi_entities")
+    a.disable_all_entities, a.prompt_ensemble = True, True
+    ents, emb = _entity_files(a, "ViT-B/16")
+    assert ents == ["apple", "zebra"] and bool((emb == 1).all())
+    assert _entity_files(args("coco_entities"), "ViT-B/16")[0] == ["cat", "dog", "hot dog"]
+    assert _entity_files(args("vinvl_vg_entities"), "ViT-B/16")[0] == ["street sign", "tree"]
+    assert _entity_files(args("visual_genome_entities"), "ViT-B/16")[0] == ["lamp", "tea pot"]
+    assert _entity_files(args("open_image_entities"), "ViT-B/16")[0] == ["ball", "bat"]
+    with pytest.raises(FileNotFoundError):
+        _entity_files(args("coco_entities"), "RN50x4")          # no embeddings pickle for that CLIP: needs the text tower
+    with pytest.raises(ValueError):
+        _entity_files(args("imagenet_entities"), "ViT-B/16")
+
+
+def test_sharded_helpers_take_the_id_width_from_the_head():
+    from types import SimpleNamespace
+    import pytest
+    import torch
+    from patchioner_amd import dist as pdist
+    assert pdist._id_columns(SimpleNamespace(viecap=None, calculate_argmax_text=False)) == 30
+    assert pdist._id_columns(SimpleNamespace(viecap=object(), calculate_argmax_text=False)) == 64
+    with pytest.raises(ValueError):
+        pdist._id_columns(SimpleNamespace(viecap=None, calculate_argmax_text=True))
+    with pytest.raises(RuntimeError):
+        pdist._last_ids(SimpleNamespace(last_ids=torch.zeros(2, 30)), 64)
