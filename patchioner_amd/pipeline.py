@@ -35,6 +35,28 @@ import torch
 _CU_STREAM_POOL: dict = {}             # (device index, first CU, CUs) -> [raw stream handles not in use]
 
 
+class BoxRegions:
+    """Region spec of a batch for the pipeline: ``model(imgs, bboxes=..., gaussian_avg=..., gaussian_bbox_variance=...)`` --
+    dense / region captioning (P/src/model.py:994-1041; BASELINE configs 3 and 4).  ``bboxes`` [B, NB, 4] xywh crop pixels; it is
+    floor-divided by the patch size IN PLACE when the batch is staged, as the reference's forward does (bbox_utils.py:19).
+    A batch contributes B * NB prefixes to its decode group and comes back as [B][NB] captions."""
+
+    def __init__(self, bboxes: torch.Tensor, gaussian_avg: bool = False, gaussian_bbox_variance: float = 0.5,
+                 use_attn_map_for_bboxes: bool = False):
+        if bboxes.dim() != 3 or bboxes.shape[-1] != 4:
+            raise ValueError("bboxes must be [B, NB, 4]")
+        self.bboxes, self.gaussian_avg, self.variance = bboxes, gaussian_avg, gaussian_bbox_variance
+        self.use_attn_map = use_attn_map_for_bboxes
+
+    @property
+    def n_boxes(self) -> int:
+        return int(self.bboxes.shape[1])
+
+
+def _rows_of(imgs, regions) -> int:
+    return imgs.shape[0] * regions.n_boxes if isinstance(regions, BoxRegions) else imgs.shape[0]
+
+
 class _Group:
     def __init__(self, cap: int, dim: int, steps: int, device):
         self.prefix = torch.empty(cap, dim, device=device, dtype=torch.float32)
@@ -50,8 +72,9 @@ class _Group:
 
 
 class TraceCaptionPipeline:
-    """``for captions in TraceCaptionPipeline(model).run(batches)`` with batches = iterable of (imgs, traces);
-    ``traces=None`` captions the CLS token instead (caption_from=cls)."""
+    """``for captions in TraceCaptionPipeline(model).run(batches)`` with batches = iterable of (imgs, regions): ``regions`` = the
+    traces of the batch (caption_from=patches), ``None`` (the CLS token, caption_from=cls) or a ``BoxRegions`` (dense / region
+    captioning: [B][NB] captions per batch).  ``RegionCaptionPipeline`` is the same class under the name that fits boxes."""
 
     def __init__(self, model, group_batches: int = 4, use_attention_tracing: bool = False, steps: int = 30,
                  stage_replicas: Sequence = (), stage_cus: Optional[int] = None, decode_cus: Optional[int] = None,
@@ -153,12 +176,25 @@ class TraceCaptionPipeline:
                 im.record_stream(stream)
         with torch.cuda.stream(stream):
             imgs = held[0][0] if len(held) == 1 else torch.cat([h[0] for h in held], dim=0)
-            want_qkv = self.use_attention_tracing and any(h[1] is not None for h in held)
+            want_qkv = any((self.use_attention_tracing and h[1] is not None and not isinstance(h[1], BoxRegions)) or
+                           (isinstance(h[1], BoxRegions) and h[1].use_attn_map) for h in held)
             tokens_all, qkv_all = eng.vit_forward(imgs, want_qkv=want_qkv)
             s = 0
             for im, traces, g in held:
                 n = im.shape[0]
                 tokens = tokens_all[s:s + n]
+                if isinstance(traces, BoxRegions):
+                    # extract_bboxes_feats on this batch's tokens (model._bbox_feats: boxes //= patch_size in place, host draw of
+                    # the var == 0 centre cells, weights and the weighted means on the device)
+                    attn = eng.cls_attention(qkv_all[s:s + n], tokens)[0] if traces.use_attn_map else None
+                    emb = m._bbox_feats(tokens, traces.bboxes, traces.gaussian_avg, traces.variance, False, attn)
+                    emb = emb.reshape(-1, emb.shape[-1])
+                    s += n
+                    g.rows += emb.shape[0]
+                    g.counts.append((n, traces.n_boxes))
+                    g.pending.append((emb, stream, m))
+                    self._flush(g)                 # a batch of boxes is many queries already: projected on its own
+                    continue
                 if traces is None:
                     emb = tokens[:, 0].contiguous()
                 else:
@@ -169,7 +205,7 @@ class TraceCaptionPipeline:
                     emb = eng.region_reduce(tokens, grids, None, 1.0 / m.num_patch_tokens)
                 s += n
                 g.rows += n
-                g.counts.append(n)
+                g.counts.append((n, None))
                 g.pending.append((emb, stream, m))
                 if len(g.pending) == self.project_batches or len(g.counts) == self.group_batches:
                     self._flush(g)
@@ -220,9 +256,13 @@ class TraceCaptionPipeline:
         rows = g.ids_host[:g.rows].tolist()
         self.last_ids = g.ids_dev
         out, s = [], 0
-        for n in g.counts:
-            out.append(self.m.tokenizer.batch_captions(rows[s:s + n], decoding_method=self.m.decoding_method))
-            s += n
+        for n, nb in g.counts:
+            k = n if nb is None else n * nb
+            caps = self.m.tokenizer.batch_captions(rows[s:s + k], decoding_method=self.m.decoding_method)
+            if nb is not None and caps is not None:        # [B][NB], as forward()'s bbox_capts (model.py:1037-1041)
+                caps = [caps[i * nb:(i + 1) * nb] for i in range(n)]
+            out.append(caps)
+            s += k
         g.rows, g.counts, g.busy, g.flushed = 0, [], False, 0
         return out
 
@@ -248,7 +288,7 @@ class TraceCaptionPipeline:
         aligned = self.vit_batches <= self.group_batches and self.group_batches % self.vit_batches == 0
         for imgs, traces in batches:
             g = self.groups[cur]
-            n = imgs.shape[0]
+            n = _rows_of(imgs, traces)
             if n > g.prefix.shape[0]:
                 raise ValueError("batch of %d does not fit the %d-prefix decode group" % (n, g.prefix.shape[0]))
             if n_assigned and rows_assigned + n > g.prefix.shape[0]:    # a larger batch than the last one: close the group first
@@ -282,3 +322,6 @@ class TraceCaptionPipeline:
         while pending:
             for caps in self._collect(pending.popleft()):
                 yield caps
+
+
+RegionCaptionPipeline = TraceCaptionPipeline

@@ -494,3 +494,35 @@ def test_clip_vit_backbone_decap_original_config(O):
     assert torch.equal(m.preprocess_images([raw]).cpu()[0], host)
     assert abs(float(host.mean()) - float((torch.from_numpy(np.asarray(Image.fromarray(raw).resize((280, 224), Image.BICUBIC).crop((28, 0, 252, 224)), dtype=np.float32).transpose(2, 0, 1) / 255.0)
                                            - torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(3, 1, 1)).div(torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(3, 1, 1)).mean())) < 1e-4
+
+
+def test_box_pipeline_matches_synchronous_forward():
+    """pipeline.RegionCaptionPipeline with BoxRegions (dense / region captioning, BASELINE configs 3 and 4: ViT + box weights +
+    weighted means + projection of batch i+1 under the greedy decode of batch i) returns exactly forward(bboxes=...)'s nested
+    [B][NB] captions, batch by batch; gaussian, uniform and attention-map weights; ragged batches; boxes mixed with trace
+    batches in one stream; the caller's boxes floor-divided in place as the reference's forward does."""
+    from patchioner_amd.pipeline import RegionCaptionPipeline, BoxRegions
+    m = _model(224, True, max_batch=8)
+    rng = np.random.RandomState(11)
+    batches, raw = [], []
+    for i, (b, nb) in enumerate([(4, 6), (8, 4), (3, 6), (2, 16), (5, 3)]):
+        imgs = W.synth_images(200 + i, b, 224).cuda()
+        xy = rng.randint(0, 12, size=(b, nb, 2)) * 14.0
+        wh = rng.randint(1, 6, size=(b, nb, 2)) * 14.0 + rng.randint(0, 14, size=(b, nb, 2))
+        raw.append((imgs, torch.tensor(np.concatenate([xy, wh], -1), dtype=torch.float32)))
+    for kw in (dict(gaussian_avg=True, gaussian_bbox_variance=1.0), dict(), dict(use_attn_map_for_bboxes=True)):
+        want = [m(imgs, get_cls_capt=False, bboxes=bx.clone(), **kw)["bbox_capts"] for imgs, bx in raw]
+        mine = [bx.clone() for _, bx in raw]
+        got = list(RegionCaptionPipeline(m, group_batches=2).run((imgs, BoxRegions(bx, **kw)) for (imgs, _), bx in zip(raw, mine)))
+        assert got == want
+        assert all(torch.equal(a, bx // 14) for a, (_, bx) in zip(mine, raw))
+        pipe = RegionCaptionPipeline(m, group_batches=1, decode_clones=1)          # config 3's setting: one batch per decode
+        assert list(pipe.run((imgs, BoxRegions(bx.clone(), **kw)) for imgs, bx in raw)) == want
+        pipe.close()
+    # boxes and traces in one stream
+    traces = [gc.block_trace(2, 3)] * 4
+    mixed = [(raw[0][0], BoxRegions(raw[0][1].clone(), gaussian_avg=True)), (raw[0][0], traces), (raw[2][0], BoxRegions(raw[2][1].clone()))]
+    got = list(RegionCaptionPipeline(m, group_batches=3).run(mixed))
+    assert got[0] == m(raw[0][0], get_cls_capt=False, bboxes=raw[0][1].clone(), gaussian_avg=True)["bbox_capts"]
+    assert got[1] == m(raw[0][0], get_cls_capt=False, traces=traces)["trace_capts"]
+    assert got[2] == m(raw[2][0], get_cls_capt=False, bboxes=raw[2][1].clone())["bbox_capts"]
