@@ -50,6 +50,9 @@ __device__ unsigned long long* roll_stamps = nullptr;
 #define ROLL_STAMP(i) do { } while (0)
 #endif
 
+#ifndef PIO_ROLL_GELU_PACKED     // GELU in the hooks on packed fp32 (fewer issue cycles, no overlap with MFMAs) or plain VALU
+#define PIO_ROLL_GELU_PACKED 0   // measured: no difference (fc1 at 80 images 123.9 vs 122.9 us; last K-tile 13.1 k vs 12.6 k cycles)
+#endif
 #ifndef PIO_ROLL_ABL             // diagnostic ablations (bit 0: bias = 0 without its scalar loads; bit 1: E3 without its global stores)
 #define PIO_ROLL_ABL 0
 #endif
@@ -246,7 +249,10 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
         float v0 = acc[q][rt][4 * a], v1 = acc[q][rt][4 * a + 1], v2 = acc[q][rt][4 * a + 2], v3 = acc[q][rt][4 * a + 3];   \
         if constexpr (EPI == EPI_GELU) {                                                                                    \
           if (g.act == 1) { v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3); }           \
-          else { v0 = gelu_erf_plain(v0); v1 = gelu_erf_plain(v1); v2 = gelu_erf_plain(v2); v3 = gelu_erf_plain(v3); }      \
+          else if (PIO_ROLL_GELU_PACKED) {                                                                                  \
+            const pio_f32x2 g01 = gelu_erf2((pio_f32x2){v0, v1}), g23 = gelu_erf2((pio_f32x2){v2, v3});                     \
+            v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];                                                             \
+          } else { v0 = gelu_erf_plain(v0); v1 = gelu_erf_plain(v1); v2 = gelu_erf_plain(v2); v3 = gelu_erf_plain(v3); }    \
         }                                                                                                                   \
         half4_t o;                                                                                                          \
         o[0] = (T)v0; o[1] = (T)v1; o[2] = (T)v2; o[3] = (T)v3;                                                             \
