@@ -119,7 +119,9 @@ int pio_finalize_weights(pio_handle h);
 
 /* -- a9 state: the text memory bank (Im2TxtProjector.embs_dataset,
  *    P/src/decap/im2txtprojection/im2txtprojection.py:341-349).  Rows with zero norm are dropped as
- *    the reference does; inverse norms are precomputed once.  `rows_kept` may be NULL. */
+ *    the reference does; inverse norms are precomputed once.  `rows_kept` may be NULL.
+ *    Device memory: the fp32 copy (rows * dim * 4 B) and, unless vit_operand_type = 2 (the exact mode), a second image of the
+ *    same size -- each row as the fp16 hi / lo halves of row * 2^k -- which is what pio_mem_project streams. */
 int pio_set_memory_bank(pio_handle h, const float* host_bank, int64_t rows, int32_t dim, int64_t* rows_kept);
 
 /* Same, from a device-resident fp32 bank (copied; no zero-row filtering -- the caller guarantees none). */
@@ -172,6 +174,9 @@ int pio_gaussian_map(pio_handle h, float variance, float* map_dev, pio_stream st
 
 /* -- a9: memory projection (Im2TxtProjector.project, im2txtprojection.py:353-385), one pass over the bank
  *    with an online softmax.  q_dev [N,D] is L2-normalised IN PLACE (reference line 368).
+ *    Arithmetic: operands as fp16 hi + lo pairs (22 significant bits), products on the fp16 matrix pipe, fp32
+ *    accumulation, fp32 softmax: as close to an fp64 evaluation as an fp32 evaluation is; with
+ *    vit_operand_type = 2 every product is an fp32 FMA in the reference's order.
  *    out_dev [N,D]; normalize != 0 L2-normalises the result; best_sims_dev [N,n_best] (may be NULL)
  *    receives the n_best largest cosine similarities in descending order. */
 int pio_mem_project(pio_handle h, float* q_dev, int32_t N, float temperature, int32_t normalize,

@@ -138,6 +138,8 @@ struct pio_context {
   static constexpr size_t kMaxPGraphs = 12;
   // memory bank
   float* bank = nullptr; float* bank_inv = nullptr; int64_t bank_rows = 0; int bank_dim = 0;
+  float bank_scale = 0.f;   // > 0: the projection runs on split fp16 operands of bank * bank_scale (project.hip) ...
+  float* bank_split = nullptr;   // ... [rows][2][dim] fp16 (hi plane, lo plane), the same bytes again as the fp32 bank
   float *part_acc = nullptr, *part_ml = nullptr, *sims = nullptr;
   int parts = 512;   // two k_project workgroups per CU
   // device-side image transforms (pio_preprocess): growable intermediate image, a ring of table slots
@@ -794,6 +796,29 @@ static int bank_common(pio_context* c, int64_t rows, int32_t dim) {
   int rc;
   if ((rc = c->dmalloc(&c->bank_inv, (size_t)rows))) return rc;
   HIP_OK(launch_row_inv_norm(c->bank, rows, dim, c->bank_inv, nullptr));
+  // the scale of the split-fp16 GEMM2: the power of two that brings the bank's largest magnitude into (2^14, 2^15].  Not in the
+  // fp32 parity mode (vit_operand_type 2: every stage exact), not for a bank with a non-finite or vanishing maximum.
+  c->bank_scale = 0.f;
+  if (c->cfg.vit_operand_type != 2 && getenv("PIO_PROJECT_EXACT") == nullptr) {
+    uint32_t* d_max = nullptr;
+    HIP_OK(hipMalloc(&d_max, 4));
+    uint32_t bits = 0;
+    hipError_t e = launch_abs_max(c->bank, rows * dim, d_max, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(&bits, d_max, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_max);
+    HIP_OK(e);
+    float amax;
+    memcpy(&amax, &bits, 4);
+    int ex = 0;
+    if (bits < 0x7F800000u && amax > 0.f) {
+      (void)std::frexp(amax, &ex);                 // amax = m 2^ex, m in [0.5, 1)  =>  amax 2^(15 - ex) <= 2^15
+      if (ex > -80 && ex < 80) c->bank_scale = std::ldexp(1.0f, 15 - ex);
+    }
+    if (c->bank_scale > 0.f) {
+      if ((rc = c->dmalloc(&c->bank_split, (size_t)rows * dim))) return rc;      // rows * 2 * dim fp16
+      HIP_OK(launch_split_bank(c->bank, rows, dim, c->bank_scale, c->bank_split, nullptr));
+    }
+  }
   if ((rc = c->dmalloc(&c->part_acc, (size_t)c->parts * 16 * dim))) return rc;
   if ((rc = c->dmalloc(&c->part_ml, (size_t)c->parts * 16 * 2))) return rc;
   if ((rc = c->dmalloc(&c->sims, (size_t)16 * rows))) return rc;
@@ -1074,7 +1099,9 @@ int pio_mem_project(pio_handle c, float* q, int32_t N, float temperature, int32_
   a.bank = c->bank; a.inv_norm = c->bank_inv; a.M = c->bank_rows; a.D = c->bank_dim; a.q = q; a.N = N;
   a.temperature = temperature; a.normalize = normalize; a.out = out; a.n_best = n_best; a.best_sims = best_sims;
   a.part_acc = c->part_acc; a.part_ml = c->part_ml; a.part_best = c->sims; a.parts = c->parts; a.n_best_cap = 16;
-  const double passes = (double)((N + 15) / 16);
+  a.bank_scale = c->bank_scale; a.bank_split = c->bank_split;
+  double passes = 0;                         // bank passes as launch_mem_project makes them: 32 queries while more than 16 are left
+  for (int left = N; left > 0; left -= left > 16 ? 32 : 16) passes += 1;
   PROF(c, PIO_PROF_MEM_PROJECT, 4.0 * N * (double)c->bank_rows * c->bank_dim,
        passes * ((double)c->bank_rows * c->bank_dim * 4.0 + (double)c->bank_rows * 4.0), (hipStream_t)stream,
        launch_mem_project(a, (hipStream_t)stream));

@@ -111,12 +111,18 @@ struct ProjectArgs {
   float* part_ml;         // [parts][N][2]  (running max, running sum)
   float* part_best;       // [parts][N][n_best_cap]
   int parts; int n_best_cap;
+  float bank_scale;       // > 0 with bank_split: both GEMMs on split fp16 operands (bank * bank_scale = hi + lo; a power of two with
+  const void* bank_split; // max|bank| * scale <= 2^15; [M][2][D] fp16, launch_split_bank); 0 / null: the exact fp32 form
 };
 hipError_t launch_mem_project(const ProjectArgs& a, hipStream_t s);
 // q normalised in place, then top-k cosine similarities and their rows per query (sims_scratch: [16][M] floats)
 hipError_t launch_mem_topk(const float* bank, const float* inv_norm, int64_t M, int D, float* q, int N, int k, float* sims_scratch,
                            float* best_sims, int64_t* best_rows, hipStream_t s);
 hipError_t launch_row_inv_norm(const float* bank, int64_t M, int D, float* inv_norm, hipStream_t s);
+// out[0] = max |x[i]| as the bit pattern of a non-negative float (zeroed by the launcher); NaN / inf give >= 0x7F800000
+hipError_t launch_abs_max(const float* x, int64_t n, uint32_t* out, hipStream_t s);
+// out[row] = [fp16 hi of bank[row] * scale (D values) | fp16 lo (D values)]: the operand image of the split-fp16 projection
+hipError_t launch_split_bank(const float* bank, int64_t M, int D, float scale, void* out, hipStream_t s);
 hipError_t launch_revert(const float* x, const float* b, const float* A_pinv, int N, int D, int P, float* out,
                          hipStream_t s);
 

@@ -32,6 +32,9 @@ namespace pio {
 #ifndef PIO_PROJECT_NT
 #define PIO_PROJECT_NT 1
 #endif
+#ifndef PIO_PROJECT_SPLIT16   // 1: the 16-query pass takes the split-fp16 form as well
+#define PIO_PROJECT_SPLIT16 1
+#endif
 __device__ __forceinline__ float4 ld_stream4(const float* p) {
   if (PIO_PROJECT_NT) {
     const f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
@@ -42,6 +45,17 @@ __device__ __forceinline__ float4 ld_stream4(const float* p) {
 
 
 typedef __attribute__((address_space(3))) void* pr_lds_ptr_t;
+
+#ifdef PIO_PROJ_STAMPS            // diagnostic builds only: cycles per phase of k_project2's loop, summed over a workgroup's tiles by
+__device__ unsigned long long* proj_stamps = nullptr;   // wave 0 -> [workgroup][8] (never read by the kernel)
+#define PROJ_STAMP(i)                                                                                          \
+  do {                                                                                                         \
+    const unsigned long long _now = __builtin_readcyclecounter();                                              \
+    st_acc[i] += _now - st_last; st_last = _now;                                                               \
+  } while (0)
+#else
+#define PROJ_STAMP(i) do { } while (0)
+#endif
 
 static constexpr int PR_ROWS = 16;   // bank rows per tile
 static constexpr int PR_Q = 16;      // queries per pass
@@ -76,6 +90,35 @@ __global__ __launch_bounds__(256) void k_row_inv_norm(const float* __restrict__ 
   if ((threadIdx.x & 63) == 0) inv[row] = 1.0f / sqrtf(s);
 }
 
+// max |x| over a buffer, as the bit pattern of a non-negative float (ordering of non-negative floats = ordering of their bits)
+__global__ __launch_bounds__(256) void k_abs_max(const float* __restrict__ x, int64_t n, uint32_t* out) {
+  uint32_t m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t b = __float_as_uint(x[i]) & 0x7FFFFFFFu;
+    m = b > m ? b : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(m, o); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// The bank as split fp16 operands, built once when the bank is loaded: out[row] = [hi(x S) for the D channels | lo(x S) for the D
+// channels], hi = fp16(x S) (round to nearest), lo = fp16(x S - hi); S = bank_scale, a power of two (see k_project2's split form).
+__global__ __launch_bounds__(256) void k_split_bank(const float* __restrict__ bank, int64_t M, int D, float S, _Float16* __restrict__ out) {
+  const int64_t pairs = M * (int64_t)(D / 2);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / (D / 2);
+    const int d = (int)(i - row * (D / 2)) * 2;
+    const float2 x = *(const float2*)(bank + row * D + d);
+    const float x0 = x.x * S, x1 = x.y * S;
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    *(h2*)(out + row * 2 * D + d) = (h2){h0, h1};
+    *(h2*)(out + row * 2 * D + D + d) = (h2){l0, l1};
+  }
+}
+
 // ---- round 2: the same pass, software-pipelined -------------------------------------------------------------------
 // k_project spends a 16-row tile as  [GEMM1 -> partial S to LDS] barrier [sum, soft-max, GEMM2] barrier [registers -> LDS]
 // barrier: three barriers, a register-staged single buffer, and the MFMA pipe idle around each of them (PMC: 39-49 % busy;
@@ -96,12 +139,32 @@ __global__ __launch_bounds__(256) void k_row_inv_norm(const float* __restrict__ 
 // Tried on top and dropped: the two query groups of a workgroup half an iteration apart (group 0 soft-max + GEMM2 while
 // group 1 runs GEMM1 and vice versa, three tile buffers, bit-identical): 726 us, MFMA busy 55 % -- the SIMD issues the older
 // wave's MFMAs first, so the groups do not interleave the way the schedule wants.
-template <int D, int NQG>
+//
+// ---- round 3: both GEMMs on split fp16 operands (SPLIT = true; what every pass takes unless the context is in the exact mode) ------
+// The fp32 matrix instructions run at the fp32 VECTOR rate (64 FLOP/clk/SIMD) and nothing of the wave's VALU work overlaps them
+// (stamps: tools/microbench/project_stamps.hip), so a 32-query pass was bound by its 192 fp32 MFMAs of 32 cycles per tile and SIMD
+// (399 us of 650) plus the soft-max beside them.  An fp16 MFMA does 16x the work per cycle, but T = 0.01 multiplies a cosine's error by
+// 100, so the operands keep 22 significant bits: every factor is split into TWO fp16 values, x S = hi + lo with hi = fp16(x S) and
+// lo = fp16(x S - hi) (S a power of two: lo is a normal fp16 for every |x| >= 2^-17 max|bank|), and the products (Ah + Al)(Bh + Bl)
+// are fp16 MFMAs with fp32 accumulation: fp16 x fp16 is exact in fp32, what is lost is below 2^-22 of each factor -- against an fp64
+// evaluation the pass is as close as the fp32 form was (2.1e-7 vs 3.9e-7 max on unit-norm outputs, tools/microbench/project_time.py).
+// The BANK IS SPLIT ONCE, when it is loaded (k_split_bank: [row][hi plane D | lo plane D] fp16 of bank * bank_scale, the same 4 D
+// bytes per row; the fp32 bank stays for the exact mode and the top-k similarities), so the pass has NO conversion work:
+//   * the LDS-DMA image of a tile is unchanged (3 x 1 KiB per row), row stride 4 D + 32 B (8 dwords mod 64);
+//   * GEMM1: a lane's A fragment = 8 consecutive channels of ITS row: one ds_read_b128 from the hi plane, one from the lo plane
+//     (conflict-free with that stride); per 32 channels Bh.qh on one accumulator and Bh.ql + Bl.qh on another (Bl.ql is 2^-22 of
+//     the result); the query fragments (q 2^14 = qh + ql) are split once per pass;
+//   * GEMM2: the B fragment needs a COLUMN of the tile (4 rows of one channel, hi and lo): two ds_read_b64_tr_b16 (gfx950's
+//     transposing LDS read, 4 rows x 16 channels per 16 lanes, conflict-free with the same stride); the 32 k-slots of one
+//     v_mfma_f32_16x16x32_f16 hold the tile's 16 rows twice, [Bh | Bl], against [Ph | Ph] and then [Pl | Pl] (P 2^14 = Ph + Pl):
+//     a lane's own four P values are its A fragment, no exchange;
+//   * powers of two scale exactly: they are divided out of the similarities (inv_norm * unscale) and of the stored partials.
+template <int D, int NQG, bool SPLIT>
 __global__ __launch_bounds__(256 * NQG, 1) void k_project2(const float* __restrict__ bank, const float* __restrict__ inv_norm,
                                                            int64_t M, const float* __restrict__ q, int N, int q0,
                                                            float temperature, float* part_acc, float* part_ml, int parts,
-                                                           int slab_unit) {
-  constexpr int STRIDE = D + 4;                  // floats; +16 B skews rows across the 64 banks
+                                                           int slab_unit, float bank_scale) {
+  constexpr int STRIDE = SPLIT ? D + 8 : D + 4;  // floats; +16 B (exact) / +32 B (split: see above) skews rows across the 64 banks
   constexpr int DW = D / 4;                      // channels per wave
   constexpr int NW = 4 * NQG;                    // waves
   constexpr int NQ = PR_Q * NQG;                 // queries per pass
@@ -116,6 +179,13 @@ __global__ __launch_bounds__(256 * NQG, 1) void k_project2(const float* __restri
   const int wid = wv & 3, grp = wv >> 2;          // channel slice of the wave, query group of the wave
   float* s_red = lds + NBUF * PR_ROWS * STRIDE + grp * 4 * 256;   // [NQG][4][256]
   const int li = lane & 15, kq = lane >> 4;
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  typedef __fp16 trh4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));   // what ds_read_b64_tr_b16's builtin returns
+  typedef __attribute__((address_space(3))) trh4_t* tr_ptr_t;
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  typedef Vec8<f16>::type h8_t;
+  constexpr float P_SCALE = 16384.0f;
+  const float unscale = SPLIT ? 1.0f / (bank_scale * P_SCALE) : 1.0f;       // powers of two: exact
 
   // slab of rows for this workgroup, in units of slab_unit = 16 RT rows (the boundaries round 1's kernel had)
   const int64_t units_total = (M + slab_unit - 1) / slab_unit;
@@ -126,12 +196,33 @@ __global__ __launch_bounds__(256 * NQG, 1) void k_project2(const float* __restri
   if (u_end > units_total) u_end = units_total;
   const int64_t t_end = u_end * tpu;              // tiles past M hold copies of row M-1, masked in the soft-max (as in k_project)
 
-  float4 qreg[DW / 16];
+  float4 qreg[SPLIT ? 1 : DW / 16];             // exact form: the query's channels as fp32 B operands
+  h8_t qfh[SPLIT ? DW / 32 : 1], qfl[SPLIT ? DW / 32 : 1];   // split form: (q 2^14) = qh + ql, 8 consecutive channels per fragment
+  if constexpr (!SPLIT) {
 #pragma unroll
-  for (int c = 0; c < DW / 16; ++c) {
-    qreg[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q0 + 16 * grp + li < N)
-      qreg[c] = *(const float4*)(q + (size_t)(q0 + 16 * grp + li) * D + wid * DW + 16 * c + 4 * kq);
+    for (int c = 0; c < DW / 16; ++c) {
+      qreg[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q0 + 16 * grp + li < N)
+        qreg[c] = *(const float4*)(q + (size_t)(q0 + 16 * grp + li) * D + wid * DW + 16 * c + 4 * kq);
+    }
+  } else {
+    static_assert(!SPLIT || DW % 32 == 0, "split form: 32 channels per MFMA");
+#pragma unroll
+    for (int c = 0; c < DW / 32; ++c) {
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (q0 + 16 * grp + li < N) {
+        const float* qp = q + (size_t)(q0 + 16 * grp + li) * D + wid * DW + 32 * c + 8 * kq;
+        const float4 v0 = *(const float4*)qp, v1 = *(const float4*)(qp + 4);
+        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = v[e] * P_SCALE;            // |q| <= 1 (normalised rows)
+        const _Float16 hh = (_Float16)x;
+        qfh[c][e] = hh;
+        qfl[c][e] = (_Float16)(x - (float)hh);
+      }
+    }
   }
 
   // tile t -> buffer b: operation o covers 1 KiB of bank row o / OPR; wave wv issues o = wv, wv + NW, ...
@@ -210,6 +301,19 @@ __global__ __launch_bounds__(256 * NQG, 1) void k_project2(const float* __restri
     }                                                                                                          \
     *(f32x4*)(s_red + wid * 256 + lane * 4) = sp;                                                              \
   } while (0)
+  // SPLIT: partial S over this wave's channels from the split tile in buffer b (hi plane at byte 0 of a row, lo plane at 2 D)
+#define PIO_GEMM1_SPLIT(b)                                                                                     \
+  do {                                                                                                         \
+    const char* rb = (const char*)(s_tile + (b) * PR_ROWS * STRIDE) + li * (STRIDE * 4) + (wid * DW + 8 * kq) * 2; \
+    f32x4 sp0 = (f32x4){0.f, 0.f, 0.f, 0.f}, sp1 = (f32x4){0.f, 0.f, 0.f, 0.f};                                \
+    _Pragma("unroll") for (int c = 0; c < DW / 32; ++c) {                                                      \
+      const h8_t ah = *(const h8_t*)(rb + 64 * c), al = *(const h8_t*)(rb + 64 * c + 2 * D);                   \
+      sp0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, qfh[c], sp0, 0, 0, 0);                                  \
+      sp1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, qfl[c], sp1, 0, 0, 0);                                  \
+      sp1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, qfh[c], sp1, 0, 0, 0);                                  \
+    }                                                                                                          \
+    *(f32x4*)(s_red + wid * 256 + lane * 4) = sp0 + sp1;                                                       \
+  } while (0)
   // sum of the four partials, online soft-max for query n = li (this lane's rows are 4 kq + i): p[], alpha, m_run; the
   // row sum stays partial (rs_part) until PIO_ROWSUM
 #define PIO_SOFTMAX(t)                                                                                         \
@@ -222,7 +326,7 @@ __global__ __launch_bounds__(256 * NQG, 1) void k_project2(const float* __restri
     float tmax = -INFINITY;                                                                                    \
     const int rows_left = (int)(M - (t) * PR_ROWS < PR_ROWS ? M - (t) * PR_ROWS : PR_ROWS);   /* 16 but in the bank's last tile */ \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
-      float z = (sfull[i] * inv4[i]) / temperature;                                                            \
+      float z = (sfull[i] * (SPLIT ? inv4[i] * unscale : inv4[i])) / temperature;   /* a power of two: inv4 * unscale is exact */ \
       if (4 * kq + i >= rows_left) z = -INFINITY;                                                              \
       p[i] = z;                                                                                                \
       tmax = fmaxf(tmax, z);                                                                                   \
@@ -256,6 +360,37 @@ __global__ __launch_bounds__(256 * NQG, 1) void k_project2(const float* __restri
       acc[j] = a4;                                                                                             \
     }                                                                                                          \
   } while (0)
+  // SPLIT: Acc = Acc * alpha + (Ph + Pl)^T . (Bh + Bl) over the split tile in buffer b.  B fragment of 16 channels: lane 4 q + p of
+  // a 16-lane group hands ds_read_b64_tr_b16 the address of row 4 kq + q, channels d0 + 4 p .. + 3 and receives channel d0 + li of
+  // rows 4 kq .. 4 kq + 3 (EXEC is all ones here: no divergent code around the loop).
+#define PIO_GEMM2_SPLIT(b)                                                                                     \
+  do {                                                                                                         \
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {                                                     \
+      float al[4];                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) al[i] = __shfl(alpha, 4 * kq + i);                         \
+      _Pragma("unroll") for (int j = 0; j < DW / 16; ++j)                                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[j][i] *= al[i];                                      \
+    }                                                                                                          \
+    float px[4];                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) px[i] = p[i] * P_SCALE;                                      \
+    const h2_t ph01 = __builtin_convertvector((f2_t){px[0], px[1]}, h2_t), ph23 = __builtin_convertvector((f2_t){px[2], px[3]}, h2_t); \
+    const h2_t pl01 = __builtin_convertvector((f2_t){px[0] - (float)ph01[0], px[1] - (float)ph01[1]}, h2_t);   \
+    const h2_t pl23 = __builtin_convertvector((f2_t){px[2] - (float)ph23[0], px[3] - (float)ph23[1]}, h2_t);   \
+    const h8_t ah = {ph01[0], ph01[1], ph23[0], ph23[1], ph01[0], ph01[1], ph23[0], ph23[1]};                  \
+    const h8_t al8 = {pl01[0], pl01[1], pl23[0], pl23[1], pl01[0], pl01[1], pl23[0], pl23[1]};                 \
+    const char* cb = (const char*)(s_tile + (b) * PR_ROWS * STRIDE) + (4 * kq + (li >> 2)) * (STRIDE * 4) +    \
+                     (wid * DW + 4 * (li & 3)) * 2;                                                            \
+    _Pragma("unroll") for (int j = 0; j < DW / 16; ++j) {                                                      \
+      const trh4_t bh = __builtin_amdgcn_ds_read_tr16_b64_v4f16((tr_ptr_t)(cb + 32 * j));                     \
+      const trh4_t bl = __builtin_amdgcn_ds_read_tr16_b64_v4f16((tr_ptr_t)(cb + 32 * j + 2 * D));             \
+      const h8_t bf = {(_Float16)bh[0], (_Float16)bh[1], (_Float16)bh[2], (_Float16)bh[3],                     \
+                       (_Float16)bl[0], (_Float16)bl[1], (_Float16)bl[2], (_Float16)bl[3]};                    \
+      f32x4 a4 = acc[j];                                                                                       \
+      a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bf, a4, 0, 0, 0);                                        \
+      a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al8, bf, a4, 0, 0, 0);                                       \
+      acc[j] = a4;                                                                                             \
+    }                                                                                                          \
+  } while (0)
 #define PIO_ROWSUM()                                                                                           \
   do {                                                                                                         \
     float rs = rs_part;                                                                                        \
@@ -285,11 +420,15 @@ __global__ __launch_bounds__(256 * NQG, 1) void k_project2(const float* __restri
       PIO_LOAD_INV(t_begin);
       PIO_WAIT_VM0();
       PIO_RAW_BARRIER();
-      PIO_GEMM1(0);
+      if constexpr (SPLIT) PIO_GEMM1_SPLIT(0);
+      else PIO_GEMM1(0);
       PIO_RAW_BARRIER();
       PIO_SOFTMAX(t_begin);
     }
     int cur = 0;
+#ifdef PIO_PROJ_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
+#endif
     for (int64_t t = t_begin; t < t_end; ++t) {
       const bool more = t + 1 < t_end;
       float inv_next[4];
@@ -299,27 +438,47 @@ __global__ __launch_bounds__(256 * NQG, 1) void k_project2(const float* __restri
 #pragma unroll
         for (int i = 0; i < 4; ++i) inv_next[i] = ib[4 * kq + i < last ? 4 * kq + i : last];
       }
-      PIO_GEMM2(cur);
+      if constexpr (SPLIT) PIO_GEMM2_SPLIT(cur);
+      else PIO_GEMM2(cur);
       PIO_ROWSUM();                     // l_run of tile t, in the shadow of the MFMAs just issued
+      PROJ_STAMP(0);
       PIO_WAIT_VM0();                   // this wave's share of tile t+1 (issued an iteration ago) and inv_next
+      PROJ_STAMP(1);
       PIO_RAW_BARRIER();                // A: tile t+1 is complete, nobody reads tile t (or s_red) any more
+      PROJ_STAMP(2);
       if (t + 2 < t_end) PIO_DMA_TILE(t + 2, cur);
       if (more) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) inv4[i] = inv_next[i];
-        PIO_GEMM1(cur ^ 1);
+        if constexpr (SPLIT) PIO_GEMM1_SPLIT(cur ^ 1);
+        else PIO_GEMM1(cur ^ 1);
+        PROJ_STAMP(3);
+        PROJ_STAMP(4);
         PIO_RAW_BARRIER();              // B: the four partials of the query group are in s_red
+        PROJ_STAMP(5);
         PIO_SOFTMAX(t + 1);
+        PROJ_STAMP(6);
       }
+#ifdef PIO_PROJ_STAMPS
+      st_acc[7] += 1;
+#endif
       cur ^= 1;
     }
+#ifdef PIO_PROJ_STAMPS
+    if (proj_stamps != nullptr && tid == 0) {
+      for (int i = 0; i < 7; ++i) proj_stamps[8 * blockIdx.x + i] = st_acc[i];
+      proj_stamps[8 * blockIdx.x + 7] = st_acc[7];
+    }
+#endif
   }
 #undef PIO_DMA_TILE
 #undef PIO_DMA_ASM_S
 #undef PIO_DMA_ASM_V
 #undef PIO_GEMM1
+#undef PIO_GEMM1_SPLIT
 #undef PIO_SOFTMAX
 #undef PIO_GEMM2
+#undef PIO_GEMM2_SPLIT
 #undef PIO_ROWSUM
 #undef PIO_LOAD_INV
 #undef PIO_WAIT_VM0
@@ -330,7 +489,7 @@ __global__ __launch_bounds__(256 * NQG, 1) void k_project2(const float* __restri
 #pragma unroll
   for (int j = 0; j < DW / 16; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pa[(size_t)(4 * kq + i) * D + wid * DW + 16 * j + li] = acc[j][i];
+    for (int i = 0; i < 4; ++i) pa[(size_t)(4 * kq + i) * D + wid * DW + 16 * j + li] = SPLIT ? acc[j][i] * unscale : acc[j][i];
   if (wid == 0 && kq == 0) {
     part_ml[((size_t)blockIdx.x * NQ + 16 * grp + li) * 2 + 0] = m_run;
     part_ml[((size_t)blockIdx.x * NQ + 16 * grp + li) * 2 + 1] = l_run;
@@ -437,30 +596,32 @@ __global__ __launch_bounds__(256) void k_revert(const float* __restrict__ x, con
   if (lane == 0) out[(size_t)n * P + p] = s;
 }
 
-template <int D, int NQG>
+template <int D, int NQG, bool SPLIT>
 static hipError_t project_pass(const ProjectArgs& a, int q0, int parts, hipStream_t s) {
   constexpr int RT = NQG == 2 ? PIO_PROJECT_RT32 : 1;           // slab boundaries in units of 16 RT rows (as in rounds 1 and 2)
-  const int smem = (2 * PR_ROWS * (D + 4) + NQG * 4 * 256) * (int)sizeof(float);
+  const int smem = (2 * PR_ROWS * (D + (SPLIT ? 8 : 4)) + NQG * 4 * 256) * (int)sizeof(float);
   static bool attr_set[64] = {};                                  // function attributes are per device
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   if (!attr_set[dev & 63]) {
-    e = hipFuncSetAttribute((const void*)k_project2<D, NQG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    e = hipFuncSetAttribute((const void*)k_project2<D, NQG, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_set[dev & 63] = true;
   }
-  hipLaunchKernelGGL((k_project2<D, NQG>), dim3(parts), dim3(256 * NQG), smem, s, a.bank, a.inv_norm, a.M, a.q, a.N, q0,
-                     a.temperature, a.part_acc, a.part_ml, parts, PR_ROWS * RT);
+  hipLaunchKernelGGL((k_project2<D, NQG, SPLIT>), dim3(parts), dim3(256 * NQG), smem, s, SPLIT ? (const float*)a.bank_split : a.bank,
+                     a.inv_norm, a.M, a.q, a.N, q0,
+                     a.temperature, a.part_acc, a.part_ml, parts, PR_ROWS * RT, a.bank_scale);
   return hipGetLastError();
 }
 
 template <int NQG>
 static hipError_t project_pass_d(const ProjectArgs& a, int q0, int parts, hipStream_t s) {
+  const bool split = a.bank_scale > 0.f && a.bank_split != nullptr && (NQG == 2 || PIO_PROJECT_SPLIT16);
   switch (a.D) {
-    case 384: return project_pass<384, NQG>(a, q0, parts, s);
-    case 512: return project_pass<512, NQG>(a, q0, parts, s);
-    case 768: return project_pass<768, NQG>(a, q0, parts, s);
+    case 384: return split ? project_pass<384, NQG, true>(a, q0, parts, s) : project_pass<384, NQG, false>(a, q0, parts, s);
+    case 512: return split ? project_pass<512, NQG, true>(a, q0, parts, s) : project_pass<512, NQG, false>(a, q0, parts, s);
+    case 768: return split ? project_pass<768, NQG, true>(a, q0, parts, s) : project_pass<768, NQG, false>(a, q0, parts, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -516,6 +677,18 @@ hipError_t launch_l2norm_rows(float* x, int N, int D, hipStream_t s) {
 
 hipError_t launch_row_inv_norm(const float* bank, int64_t M, int D, float* inv_norm, hipStream_t s) {
   hipLaunchKernelGGL(k_row_inv_norm, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, bank, M, D, inv_norm);
+  return hipGetLastError();
+}
+
+hipError_t launch_split_bank(const float* bank, int64_t M, int D, float scale, void* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_split_bank, dim3(4096), dim3(256), 0, s, bank, M, D, scale, (_Float16*)out);
+  return hipGetLastError();
+}
+
+hipError_t launch_abs_max(const float* x, int64_t n, uint32_t* out, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(out, 0, 4, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_abs_max, dim3(2048), dim3(256), 0, s, x, n, out);
   return hipGetLastError();
 }
 

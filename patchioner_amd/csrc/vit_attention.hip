@@ -17,13 +17,15 @@
 //                                              is read with the same permutation), so P never visits LDS.
 // The accumulator O^T has the query on the lane as well, so rescaling by exp(m_old - m_new) is lane-local.
 //
-// Round 2.  What moved the kernel was its VALU count: on gfx950 another wave's plain VALU instructions do NOT run under an
-// MFMA (tools/microbench/mfma_valu_overlap.hip: 20.4 ms together against 11.4 + 9.7 ms alone; v_exp_f32 does overlap), so the
-// ~250 plain VALU instructions round 1 spent per 16 MFMAs were all MFMA time.  k_vit_attention's softmax is now: padding keys
-// masked only in a sequence's last tile, the scale folded into the exponent's FMA (maximum over raw scores), packed fp32
-// FMA / add, packed conversions, no rescale of O^T while no maximum moved; and a V^T row sits in LDS in the order the P^T
+// Round 2.  What moved the kernel was its VALU count (~250 VALU instructions per 16 MFMAs in round 1).  k_vit_attention's
+// softmax is now: padding keys masked only in a sequence's last tile, the scale folded into the exponent's FMA (maximum over
+// raw scores), packed conversions, no rescale of O^T while no maximum moved; and a V^T row sits in LDS in the order the P^T
 // fragment multiplies it (one ds_read_b128 per fragment, no regrouping v_movs).  64 images: 46.1 us per launch (290 TF)
 // against round 1's 51.3; 16 images 18.4 against 20.5; 518^2 x 8: 86 us (537 TF) against 105.
+// Round 3.  Round 2 had concluded that another wave's VALU never runs under an MFMA; its probe's fmaf loop had been packed by
+// hipcc.  tools/microbench/mfma_valu_overlap2.hip (opcodes pinned): plain v_fma_f32 / v_add_f32 / v_cvt_pk DO overlap another
+// wave's MFMAs, v_pk_fma_f32 / v_pk_add_f32 do NOT.  The FMAs and adds of the softmax are therefore plain instructions
+// (PIO_ATTN_PLAIN_VALU): 43.0 us at 64 images against 44.8 packed, same bits.
 // k_vit_attention2 (tools/microbench/attic/vit_attention2.hip since round 3) was a larger restructuring built before that was understood; correct (same tests), not
 // faster, kept for its measurements:
 //   * workgroup = ceil(nq / ceil(nq / 8)) waves (T = 261: 9 query tiles = two workgroups of 5 waves instead of three of 4
@@ -177,10 +179,8 @@ __global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAt
           st[kbk] = mfma32(kf, qf[s], st[kbk]);
         }
       }
-      // the softmax on half the VALU instructions (gfx950 does not overlap another wave's plain VALU with MFMAs -- tools/
-      // microbench/mfma_valu_overlap.hip: 20.4 ms together against 11.4 + 9.7 alone -- so every one of them is MFMA time):
-      // padding keys are masked only in the sequence's last tile; the scale rides in the exponent's FMA (the maximum is
-      // taken over raw scores); packed fp32 FMA / add and packed conversions; no rescale while no query's maximum moved.
+      // the lean softmax: padding keys are masked only in the sequence's last tile; the scale rides in the exponent's FMA (the
+      // maximum is taken over raw scores); packed conversions; no rescale while no query's maximum moved.
       // (Skipping the all-padding upper half of a sequence's last tile as well costs 4 more VGPRs -- 172, two waves per SIMD
       // instead of three -- and loses: 53.6 against 47.8 us at 64 images.)
       const int left = nkeys - kt * KV_TILE;              // keys of the sequence in this tile and after (block-uniform)

@@ -65,6 +65,13 @@ hipError_t launch_ctx_clean(const float*, const float*, int, int, int, int, floa
 hipError_t launch_gaussian_map(int, float, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_mem_project(const ProjectArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_mem_topk(const float*, const float*, int64_t, int, float*, int, int, float*, float*, int64_t*, hipStream_t) { return hipSuccess; }
+hipError_t launch_split_bank(const float*, int64_t, int, float, void*, hipStream_t) { return hipSuccess; }
+hipError_t launch_abs_max(const float* x, int64_t n, uint32_t* out, hipStream_t) {
+  uint32_t m = 0;
+  for (int64_t i = 0; i < n; ++i) { uint32_t b; memcpy(&b, x + i, 4); b &= 0x7FFFFFFFu; m = b > m ? b : m; }
+  *out = m;
+  return hipSuccess;
+}
 hipError_t launch_row_inv_norm(const float*, int64_t M, int, float* inv, hipStream_t) { for (int64_t i = 0; i < M; ++i) inv[i] = 1.f; return hipSuccess; }
 hipError_t launch_l2norm_rows(float*, int, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_activation_f32(float*, size_t, int, hipStream_t) { return hipSuccess; }

@@ -10,6 +10,10 @@ g = torch.Generator(device="cuda").manual_seed(6)
 M = 591753
 bank = torch.randn(M, 768, device="cuda", generator=g)
 e.set_memory_bank(bank)
+e_exact = Engine(embed_dim=768, depth=1, num_heads=12, num_registers=4, crop_dim=224, max_batch=2, max_prefixes=128, vit_dtype="fp16")
+os.environ["PIO_PROJECT_EXACT"] = "1"          # read when the bank is set
+e_exact.set_memory_bank(bank)
+del os.environ["PIO_PROJECT_EXACT"]
 for N in ([int(a) for a in sys.argv[1:]] or (16, 32, 48, 64, 128)):
     q = torch.randn(N, 768, device="cuda", generator=g)
     for _ in range(3): out = e.project(q.clone(), normalize=True)
@@ -28,12 +32,11 @@ for N in ([int(a) for a in sys.argv[1:]] or (16, 32, 48, 64, 128)):
         ref = ref * sc[:, None] + w @ b; den = den * sc + w.sum(1); mx = m2
     ref = ref / den[:, None]; ref = ref / ref.norm(dim=-1, keepdim=True)
     err = (out.double() - ref).abs().max().item()
-    # the round-1 kernel on the same input (PIO_PROJECT_V1 is read per call): time, and whether the outputs are the same bits
-    os.environ["PIO_PROJECT_V1"] = "1"
-    for _ in range(3): old = e.project(q.clone(), normalize=True)
+    # the exact form (GEMM2 on the fp32 matrix pipe) on the same input: time, error against fp64, distance between the two
+    for _ in range(3): old = e_exact.project(q.clone(), normalize=True)
     torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(10): old = e.project(q.clone(), normalize=True)
+    for _ in range(10): old = e_exact.project(q.clone(), normalize=True)
     torch.cuda.synchronize(); dt1 = (time.perf_counter() - t) / 10
-    del os.environ["PIO_PROJECT_V1"]
-    print("N=%3d: %.3f ms per call (%.3f ms per 16 queries), max |err| vs fp64 %.2e | k_project (round 1): %.3f ms, bit-identical: %s"
-          % (N, dt * 1e3, dt * 1e3 * 16 / N, err, dt1 * 1e3, bool(torch.equal(out, old))), flush=True)
+    err1 = (old.double() - ref).abs().max().item()
+    print("N=%3d: %.3f ms per call (%.3f ms per 16 queries), max |err| vs fp64 %.2e | exact fp32 GEMM2: %.3f ms, max |err| %.2e | max |split - exact| %.2e"
+          % (N, dt * 1e3, dt * 1e3 * 16 / N, err, dt1 * 1e3, err1, (out - old).abs().max().item()), flush=True)
