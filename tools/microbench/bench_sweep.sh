@@ -22,6 +22,8 @@ run "decodes 5" -- --decode-streams 5 &&
 run "4 per launch" -- --vit-batches 4 &&
 run "8 per launch" -- --vit-batches 8 &&
 run "default again" -- &&
-run "old gemm" PIO_GEMM256_MIN_TILES=0 -- &&
-run "old projection" PIO_PROJECT_V1=1 --
+run "6 batches per decode" -- --in-flight 6 &&
+run "4 batches per decode" -- --in-flight 4 &&
+run "no rolling gemm" PIO_GEMM_ROLL_MIN_TILES=1000000 -- &&
+run "exact fp32 projection" PIO_PROJECT_EXACT=1 --
 cat gpurun_out/sweep.log
