@@ -233,7 +233,8 @@ def main():
         from patchioner_amd.pipeline import TraceCaptionPipeline
         pipe = TraceCaptionPipeline(model, group_batches=P, stage_replicas=models[1:S], vit_batches=VB, decode_clones=DS - 1,
                                     stage_cus=int(os.environ.get("PIO_STAGE_CUS", "0")) or None,
-                                    decode_cus=int(os.environ.get("PIO_DECODE_CUS", "0")) or None)
+                                    decode_cus=int(os.environ.get("PIO_DECODE_CUS", "0")) or None,
+                                    eager_first=os.environ.get("PIO_BENCH_EAGER", "0") == "1")
 
     def run_steps(n):
         """n forwards.  mode=group: stage 1 (ViT .. projection) per batch, ONE decode per P batches, the two stages

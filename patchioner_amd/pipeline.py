@@ -78,7 +78,7 @@ class TraceCaptionPipeline:
 
     def __init__(self, model, group_batches: int = 4, use_attention_tracing: bool = False, steps: int = 30,
                  stage_replicas: Sequence = (), stage_cus: Optional[int] = None, decode_cus: Optional[int] = None,
-                 vit_batches: int = 1, decode_replicas: Sequence = (), decode_clones: int = 0):
+                 vit_batches: int = 1, decode_replicas: Sequence = (), decode_clones: int = 0, eager_first: bool = False):
         """``stage_replicas``: further Patchioner instances holding the SAME weights (each has its own ViT
         workspace); stage 1 of consecutive batches then alternates over the replicas, each on its own stream,
         so that one batch's GEMM tails, epilogues and launch gaps are filled by the other's kernels."""
@@ -92,6 +92,11 @@ class TraceCaptionPipeline:
         self._own_clones = [model.engine.clone_decoder() for _ in range(max(0, int(decode_clones)))]
         self.decode_engines = [model.engine] + [getattr(r, "engine", r) for r in decode_replicas] + self._own_clones
         self.group_batches = group_batches
+        # eager_first: a group is decoded early, with the batches staged so far, whenever NO decode is in flight (run()).  Off by
+        # default: measured on the bench workload it LOSES (20 steps: 6.52 k against 7.44 k captions/s; 128 steps: 7.53 against 7.63 k)
+        # -- the early, smaller decode shares the chip with the next ViT launches and stretches both, and the stream's last group
+        # grows.  It is for sources slower than the decoders (time to first caption), not for throughput.
+        self.eager_first = bool(eager_first)
         self.vit_batches = max(1, int(vit_batches))
         self._held: List = []             # batches waiting for their shared ViT launch
         # batches whose embeddings share one projection call: one 32-query bank pass serves two batches (0.44 instead
@@ -277,9 +282,18 @@ class TraceCaptionPipeline:
         n_assigned, rows_assigned = 0, 0
 
         def launch_held():
+            nonlocal cur, n_assigned, rows_assigned
             if self._held:
                 self._stage(self._held)
                 self._held = []
+            # Nothing is decoding (the start of a stream, or a source slower than the decoders) and the open group has staged
+            # batches: decode them now rather than keep every decoder idle until the group is full.  In the steady state a decode
+            # is always in flight and groups fill up as before; the captions do not depend on the grouping either way.
+            if (getattr(self, "eager_first", False) and not closing and n_assigned
+                    and all(gg.decoded.query() for gg in pending)):
+                closing.append(self.groups[cur])
+                cur = (cur + 1) % len(self.groups)
+                n_assigned, rows_assigned = 0, 0
             for gg in closing:
                 self._decode(gg)
                 pending.append(gg)

@@ -10,15 +10,26 @@ import torch
 from patchioner_amd import pipeline as P
 
 
+class _Ev:
+    """Stand-in for the group's `decoded` event: query() says whether the decode has finished (drawn at random when asked)."""
+    def __init__(self, rnd):
+        self.rnd = rnd
+
+    def query(self):
+        return self.rnd is None or self.rnd.random() < 0.5
+
+
 class _G:
-    def __init__(self, cap):
+    def __init__(self, cap, rnd=None):
         self.prefix = torch.empty(cap, 1)
         self.rows, self.counts, self.busy, self.items = 0, [], False, []
+        self.decoded = _Ev(rnd)
 
 
-def _make(gb, vb, ngroups, cap=64):
+def _make(gb, vb, ngroups, cap=64, eager=None):
     p = P.TraceCaptionPipeline.__new__(P.TraceCaptionPipeline)
-    p.groups = [_G(cap) for _ in range(ngroups)]
+    p.groups = [_G(cap, eager) for _ in range(ngroups)]
+    p.eager_first = eager is not None
     p.group_batches, p.vit_batches, p._held = gb, vb, []
     launches = []
 
@@ -64,3 +75,23 @@ def test_bench_setting_fills_every_vit_launch():
     # aligned settings behave as before: a group's last launch goes out with its last batch
     p, launches = _make(8, 4, 4, cap=128)
     assert [c[0] for c in p.run((torch.empty(16, 1), i) for i in range(20))] == list(range(20)) and launches == [4] * 5
+
+
+def test_eager_first_group_keeps_order_and_never_overflows():
+    """eager_first: the open group is decoded early whenever no decode is in flight (here: whenever the stand-in events say so,
+    at random) -- any such regrouping must still return every batch once, in order, within the buffers."""
+    rnd = random.Random(7)
+    for gb, vb, ng in itertools.product((1, 2, 4, 8), (1, 2, 4, 5, 8), (2, 3, 4)):
+        for _ in range(6):
+            sizes = [rnd.choice((1, 3, 8, 16, 16, 16)) for _ in range(rnd.randint(0, 23))]
+            p, _ = _make(gb, vb, ng, eager=random.Random(rnd.random()))
+            got = [c[0] for c in p.run((torch.empty(n, 1), i) for i, n in enumerate(sizes))]
+            assert got == list(range(len(sizes))), (gb, vb, ng, sizes, got)
+    # the start of a stream: the first ViT launch's batches are decoded at once (no decode in flight), later groups fill up
+    p, launches = _make(8, 5, 4, cap=128, eager=None)
+    p.eager_first = True
+    sizes_decoded = []
+    dec = p._decode
+    p._decode = lambda g: (sizes_decoded.append(len(g.counts)), dec(g))[1]
+    got = [c[0] for c in p.run((torch.empty(16, 1), i) for i in range(20))]
+    assert got == list(range(20)) and sizes_decoded[0] == 5 and sum(sizes_decoded) == 20
