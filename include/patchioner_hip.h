@@ -230,7 +230,8 @@ int pio_lm_score(pio_handle h, const int32_t* tokens, const int32_t* lens, int32
 
 /* word_embed + torch.cat + greedy_search (entrypoint.py:126-150, search.py:108-191): cont [N, Lc, 768] soft prompt,
  * tokens [N, Lt] int32 hard-prompt ids already padded to one length (pad_sequence), soft_first as in the config; `steps`
- * greedy tokens (64 in the reference) with a KV cache, no attention mask, no early stop -> ids [N, steps] int32. */
+ * greedy tokens (64 in the reference) with a KV cache, no attention mask, no early stop -> ids [N, steps] int32.
+ * cont == NULL: only_hard_prompt (entrypoint.py:130-131) -- the prompt is the word embeddings of `tokens` alone (Lt >= 1). */
 int pio_viecap_decode(pio_handle h, const float* cont, const int32_t* tokens, int32_t N, int32_t Lt, int32_t soft_first,
                       int32_t steps, int32_t* ids, pio_stream stream);
 

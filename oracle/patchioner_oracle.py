@@ -720,7 +720,7 @@ class ViECapOracle:
     def __init__(self, w: Dict[str, torch.Tensor], tokenizer, entities_text: Sequence[str], texts_embeddings: torch.Tensor,
                  continuous_prompt_length: int = 10, clip_project_length: int = 10, temperature: float = 0.01, top_k: int = 3,
                  threshold: float = 0.2, using_hard_prompt: bool = False, soft_prompt_first: bool = False,
-                 map_heads: int = 8, gpt_heads: int = 12):
+                 map_heads: int = 8, gpt_heads: int = 12, only_hard_prompt: bool = False):
         self.w = {k: v.detach().float().cpu() for k, v in w.items()}
         self.tok = tokenizer
         self.entities_text = list(entities_text)
@@ -728,6 +728,7 @@ class ViECapOracle:
         self.Lc, self.Lp = continuous_prompt_length, clip_project_length
         self.temperature, self.top_k, self.threshold = temperature, top_k, threshold
         self.using_hard_prompt, self.soft_prompt_first = using_hard_prompt, soft_prompt_first
+        self.only_hard_prompt = only_hard_prompt                      # entrypoint.py:130-131: the word embeddings alone
         self.map_heads = map_heads
         self.gpt = DeCapOracle({("decoder." + k[4:]): v for k, v in self.w.items() if k.startswith("gpt.")}, n_head=gpt_heads)
         self.map_layers = 1 + max(int(k.split(".")[3]) for k in self.w if k.startswith("mapping_network.transformer.layers."))
@@ -799,7 +800,10 @@ class ViECapOracle:
             for i, r in enumerate(rows):
                 tokens[i, :len(r)] = torch.tensor(r)
             disc = wte[tokens]
-            emb = torch.cat((cont, disc), dim=1) if self.soft_prompt_first else torch.cat((disc, cont), dim=1)
+            if self.only_hard_prompt:                                  # entrypoint.py:130-131
+                emb = disc
+            else:
+                emb = torch.cat((cont, disc), dim=1) if self.soft_prompt_first else torch.cat((disc, cont), dim=1)
             self.last["entity_probs"] = probs
         else:
             emb = cont

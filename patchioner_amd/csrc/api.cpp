@@ -1265,10 +1265,12 @@ int pio_lm_score(pio_handle c, const int32_t* tokens, const int32_t* lens, int32
 
 int pio_viecap_decode(pio_handle c, const float* cont, const int32_t* tokens, int32_t N, int32_t Lt, int32_t soft_first,
                       int32_t steps, int32_t* ids, pio_stream stream) {
-  if (!c || !cont || !ids || (Lt > 0 && !tokens)) return fail(PIO_ERR_INVALID_ARG, "pio_viecap_decode: null argument");
-  if (!c->has_dec || !c->has_map) return fail(PIO_ERR_NOT_READY, "pio_viecap_decode: language model / mapping network not loaded");
+  if (!c || !ids || (Lt > 0 && !tokens)) return fail(PIO_ERR_INVALID_ARG, "pio_viecap_decode: null argument");
+  if (!cont && Lt < 1) return fail(PIO_ERR_INVALID_ARG, "pio_viecap_decode: neither a soft prompt nor prompt tokens");
+  if (!c->has_dec || (cont && !c->has_map)) return fail(PIO_ERR_NOT_READY, "pio_viecap_decode: language model / mapping network not loaded");
   if (N < 1 || N > c->cfg.max_prefixes) return fail(PIO_ERR_CAPACITY, "pio_viecap_decode: N above max_prefixes");
-  const int P = c->map_Lc + Lt;
+  const int Lc = cont ? c->map_Lc : 0;       // cont == NULL: only_hard_prompt (entrypoint.py:130-131), the word embeddings alone
+  const int P = Lc + Lt;
   if (Lt < 0 || steps < 1 || steps > 64 || P + steps - 1 > c->cfg.max_steps)
     return fail(PIO_ERR_CAPACITY, "pio_viecap_decode: prompt + generated positions above max_steps");
   HIP_OK(hipSetDevice(c->cfg.device));
@@ -1280,7 +1282,7 @@ int pio_viecap_decode(pio_handle c, const float* cont, const int32_t* tokens, in
     if ((rc = c->dmalloc(&c->tok_buf, (size_t)c->cfg.max_prefixes * c->cfg.max_steps))) return rc;
   }
   if (Lt > 0) HIP_OK(hipMemcpyAsync(c->tok_buf, tokens, (size_t)N * Lt * 4, hipMemcpyDeviceToDevice, s));
-  HIP_OK(launch_build_prompt(cont, c->tok_buf, c->wte, N, c->map_Lc, Lt, E, c->cfg.dec_vocab, soft_first, c->prompt_buf, s));
+  HIP_OK(launch_build_prompt(cont, c->tok_buf, c->wte, N, Lc, Lt, E, c->cfg.dec_vocab, soft_first, c->prompt_buf, s));
   DecoderArgs a;
   a.N = N; a.steps = steps; a.E = E; a.heads = c->cfg.dec_heads; a.layers = c->cfg.dec_layers; a.vocab = c->cfg.dec_vocab;
   a.prefix_size = c->cfg.prefix_size; a.eps = c->cfg.dec_ln_eps; a.prefix = nullptr; a.clip_w = nullptr; a.clip_b = nullptr;

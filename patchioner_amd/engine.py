@@ -402,15 +402,19 @@ class Engine:
             check(self.lib.pio_lm_score(self.h, ptr(tok_d), ptr(lens_d), len(chunk), L, ptr(out[s:s + cap]), _stream()))
         return out
 
-    def viecap_decode(self, cont: torch.Tensor, tokens: Optional[torch.Tensor], soft_first: bool = True, steps: int = 64) -> torch.Tensor:
-        """cont [N, Lc, E] device, tokens [N, Lt] int32 (host or device) or None -> greedy ids [N, steps] int32."""
-        N = cont.shape[0]
+    def viecap_decode(self, cont: Optional[torch.Tensor], tokens: Optional[torch.Tensor], soft_first: bool = True, steps: int = 64) -> torch.Tensor:
+        """cont [N, Lc, E] device (None: only_hard_prompt, the prompt is the tokens' word embeddings alone), tokens [N, Lt] int32
+        (host or device) or None -> greedy ids [N, steps] int32."""
         tok = self._dev(tokens, torch.int32) if tokens is not None else None
+        if cont is None and tok is None:
+            raise ValueError("viecap_decode: neither a soft prompt nor prompt tokens")
+        N = cont.shape[0] if cont is not None else tok.shape[0]
         Lt = int(tok.shape[1]) if tok is not None else 0
         ids = torch.empty(N, steps, device=self.device, dtype=torch.int32)
         for s in range(0, N, self.max_prefixes):
             e = min(N, s + self.max_prefixes)
-            check(self.lib.pio_viecap_decode(self.h, ptr(cont[s:e].contiguous()), ptr(tok[s:e].contiguous()) if tok is not None else None,
+            check(self.lib.pio_viecap_decode(self.h, ptr(cont[s:e].contiguous()) if cont is not None else None,
+                                             ptr(tok[s:e].contiguous()) if tok is not None else None,
                                              e - s, Lt, 1 if soft_first else 0, int(steps), ptr(ids[s:e]), _stream()))
         return ids
 

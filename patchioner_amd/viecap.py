@@ -260,7 +260,7 @@ class VieCapHead:
                 tokens[i, :len(r)] = torch.tensor(r, dtype=torch.int32)
             self.last_prompt_tokens = tokens
         if a.using_hard_prompt and a.only_hard_prompt:
-            raise NotImplementedError("only_hard_prompt (no soft prompt in the sequence)")
+            cont = None                                                  # entrypoint.py:130-131: the word embeddings alone
         ids = eng.viecap_decode(cont, tokens, soft_first=bool(a.soft_prompt_first) or tokens is None, steps=64)
         self.last_ids = ids
         rows = ids.cpu().tolist()

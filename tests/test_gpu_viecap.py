@@ -143,6 +143,26 @@ def test_viecap_soft_prompt_only_and_routing_through_forward(O, case):
     assert len(out["cls_capt"]) == 3 and len(out["trace_capts"]) == 3 and all(isinstance(s, str) for s in out["cls_capt"] + out["trace_capts"])
 
 
+def test_viecap_only_hard_prompt_vs_the_oracle(O, case):
+    """only_hard_prompt (entrypoint.py:130-131): the prompt is the word embeddings of the entity sentence alone -- no soft
+    prompt in the sequence (pio_viecap_decode with cont == NULL); prompt tokens and ids against the oracle."""
+    w, tok, ents, emb, x = case
+    c = gc.VIECAP
+    kw = dict(temperature=c["temperature"], top_k=c["top_k"], threshold=c["threshold"], using_hard_prompt=True)
+    m = _model(_viecap_cfg(w, tok, ents, emb, c["C"], only_hard_prompt=True, **kw))
+    orc = O.ViECapOracle(w, tok, ents, emb, only_hard_prompt=True, **kw)
+    want = orc.forward(x[:4].clone())
+    got = m.viecap.forward(x[:4].clone())
+    assert np.array_equal(m.viecap.last_prompt_tokens.numpy(), orc.last["prompt_tokens"].numpy())
+    ids = m.viecap.last_ids.cpu().long()
+    _explained(orc.last["margins"], ids, orc.last["ids"], "ViECap only_hard_prompt vs the oracle")
+    if torch.equal(ids, orc.last["ids"]):
+        assert got == want
+    # the C-ABI refuses a call with neither kind of prompt
+    with pytest.raises(Exception):
+        m.engine.viecap_decode(None, None)
+
+
 def test_config5_shape_vitl14_fp16_attention_weighted_traces(O):
     """BASELINE config 5 on one GPU's shard: ViT-L/14 (D = 1024, 2 of its 24 blocks here), fp16 operands, 16 images,
     attention-weighted trace regions into the ViECap head (clip_hidden_size 1024, entity matrix [K, 1024]): the decoder
