@@ -235,6 +235,27 @@ int pio_lm_score(pio_handle h, const int32_t* tokens, const int32_t* lens, int32
 int pio_viecap_decode(pio_handle h, const float* cont, const int32_t* tokens, int32_t N, int32_t Lt, int32_t soft_first,
                       int32_t steps, int32_t* ids, pio_stream stream);
 
+/* beam_search (P/src/viecap/search.py:193-285; VieCap.forward calls it per image when using_greedy_search is false,
+ * entrypoint.py:143-148) as three device steps; the bookkeeping between them (token lists, lengths, stop flags) is the caller's.
+ * The W beams of an image are the N rows of these calls and keep KV caches on the handle (the reference re-runs every beam's whole
+ * sequence each step).  N <= min(16, max_prefixes); logp_dev [N, vocab] receives log(softmax(logits)) of the next token, evaluated
+ * as the reference does (softmax, then log).
+ *   pio_lm_prefill: embeds_dev [N, P, 768] (the prompt, repeated per beam) at positions 0..P-1.
+ *   pio_lm_advance: beams re-ordered first -- row n continues the sequence of row src_rows_dev[n] (NULL: no re-ordering) -- then
+ *     tokens_dev[n] (int32) is appended at position `pos` (= P + tokens generated so far - 1 ... the position of the new token).
+ *   pio_beam_select: one selection.  scores_dev == NULL: the first one, the W largest of row 0.  Otherwise candidate (b, v) =
+ *     stopped[b] ? (v == 0 ? scores[b] / lens[b] : -inf) : (scores[b] + logp[b][v]) / (lens[b] + 1); the W largest in descending
+ *     order (ties: lower b * vocab + v first) -> out_val_dev [W] fp32, out_idx_dev [W] int64 flat indices. */
+/* word_embed + torch.cat alone (entrypoint.py:126-135): prompt_dev [N, Lc + Lt, 768] as pio_viecap_decode assembles it
+ * (cont_dev NULL: only_hard_prompt, Lc = 0); what beam search starts from. */
+int pio_viecap_build_prompt(pio_handle h, const float* cont_dev, const int32_t* tokens_dev, int32_t N, int32_t Lt, int32_t soft_first,
+                            float* prompt_dev, pio_stream stream);
+int pio_lm_prefill(pio_handle h, const float* embeds_dev, int32_t N, int32_t P, float* logp_dev, pio_stream stream);
+int pio_lm_advance(pio_handle h, const int32_t* tokens_dev, const int32_t* src_rows_dev, int32_t N, int32_t pos, float* logp_dev,
+                   pio_stream stream);
+int pio_beam_select(pio_handle h, const float* logp_dev, const float* scores_dev, const float* lens_dev, const int32_t* stopped_dev,
+                    int32_t W, float* out_val_dev, int64_t* out_idx_dev, pio_stream stream);
+
 /* -- measurement: live HIP-event timing of the launches a call makes, on the stream they are launched on.
  *    While enabled every bracketed launch records a (start, stop) event pair; pio_profile_read waits for the
  *    recorded events of one class and returns the summed device time, the launch count and the ALGORITHMIC

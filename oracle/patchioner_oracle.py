@@ -836,6 +836,81 @@ class ViECapOracle:
             out.append(self.tok.decode(r[:i + 1]))
         return out
 
+    def prompt_embeddings(self, image_features: torch.Tensor) -> torch.Tensor:
+        """entrypoint.py:108-135 alone: the prompt the search starts from ([N, P, E]; features normalised in place)."""
+        pad_id = self.tok.pad_token_id if self.tok.pad_token_id is not None else 0
+        image_features /= image_features.norm(2, dim=-1, keepdim=True)
+        cont = self.mapping_network(image_features)
+        if not self.using_hard_prompt:
+            return cont
+        wte = self.gpt.w["decoder.transformer.wte.weight"]
+        probs = self.entity_probs(image_features)
+        rows = [self.tok.encode(self.prompt_text(self.detect(probs[i]))) for i in range(image_features.shape[0])]
+        L = max(len(r) for r in rows)
+        tokens = torch.full((len(rows), L), pad_id, dtype=torch.long)
+        for i, r in enumerate(rows):
+            tokens[i, :len(r)] = torch.tensor(r)
+        disc = wte[tokens]
+        if self.only_hard_prompt:
+            return disc
+        return torch.cat((cont, disc), dim=1) if self.soft_prompt_first else torch.cat((disc, cont), dim=1)
+
+    def beam_search(self, embeddings: torch.Tensor, beam_width: int = 5, max_len: int = 64, end_of_sentences=(".", " .")) -> List[str]:
+        """``beam_search`` (P/src/viecap/search.py:193-285) for one prompt [1, P, E], statement by statement; the only change is
+        that the language model keeps a KV cache (re-indexed by ``next_tokens_source``) instead of re-running every beam's whole
+        sequence -- the same logits (the reference's greedy search itself uses the cache).  ``self.last_beam``: per beam, in the
+        order of the last selection, (ids, length, score), the order returned, and per selection the margin between the last
+        chosen and the first rejected candidate."""
+        wte = self.gpt.w["decoder.transformer.wte.weight"]
+        eos = [self.tok.encode(e)[-1] for e in end_of_sentences]
+        scores = None
+        tokens = None
+        seq_lengths = torch.ones(beam_width)
+        is_stopped = torch.zeros(beam_width, dtype=torch.bool)
+        generated_new = embeddings.float()                       # the positions not yet run through the model
+        past = None
+        margins = []
+        for i in range(max_len):
+            logits, past = self.gpt.gpt2_logits_cached(generated_new, past)     # :244-245, last position
+            logits = logits / 1.0                                               # temperature 1.0
+            logits = logits.softmax(-1).log()                                   # :246
+            if scores is None:
+                top = logits.topk(beam_width + 1, -1)
+                margins.append(float(top.values[0, beam_width - 1] - top.values[0, beam_width]))
+                scores, next_tokens = logits.topk(beam_width, -1)               # :248
+                past = [(k.expand(beam_width, *k.shape[1:]), v.expand(beam_width, *v.shape[1:])) for k, v in past]   # :249 generated.expand
+                next_tokens, scores = next_tokens.permute(1, 0), scores.squeeze(0)
+                tokens = next_tokens
+            else:
+                logits[is_stopped] = -float("inf")
+                logits[is_stopped, 0] = 0
+                scores_sum = scores[:, None] + logits
+                seq_lengths[~is_stopped] += 1
+                scores_sum_average = scores_sum / seq_lengths[:, None]
+                top = scores_sum_average.view(-1).topk(beam_width + 1, -1)
+                margins.append(float(top.values[beam_width - 1] - top.values[beam_width]))
+                scores_sum_average, next_tokens = scores_sum_average.view(-1).topk(beam_width, -1)
+                next_tokens_source = torch.div(next_tokens, scores_sum.shape[1], rounding_mode="trunc")
+                seq_lengths = seq_lengths[next_tokens_source]
+                next_tokens = next_tokens % scores_sum.shape[1]
+                next_tokens = next_tokens.unsqueeze(1)
+                tokens = tokens[next_tokens_source]
+                tokens = torch.cat((tokens, next_tokens), dim=1)
+                past = [(k[next_tokens_source], v[next_tokens_source]) for k, v in past]        # :267 generated[next_tokens_source]
+                scores = scores_sum_average * seq_lengths
+                is_stopped = is_stopped[next_tokens_source]
+            generated_new = wte[next_tokens.squeeze()].view(beam_width, 1, -1)  # :271-274
+            is_stopped = is_stopped + (next_tokens.eq(eos[0]) | next_tokens.eq(eos[1])).squeeze()
+            if is_stopped.all():
+                break
+        scores = scores / seq_lengths
+        output_list = tokens.numpy()
+        texts = [self.tok.decode([int(t) for t in out[:int(n)]]) for out, n in zip(output_list, seq_lengths)]
+        order = scores.argsort(descending=True)
+        self.last_beam = dict(ids=[[int(t) for t in out[:int(n)]] for out, n in zip(output_list, seq_lengths)],
+                              lengths=seq_lengths.clone(), scores=scores.clone(), order=order.tolist(), margins=margins)
+        return [texts[i] for i in order]
+
     def compute_perplexity(self, sentences) -> List[float]:
         """``VieCap.compute_perplexity`` (P/src/viecap/entrypoint.py:155-172): each sentence is tokenised again and run
         through the language model with ``labels = input_ids``: loss = mean cross-entropy of token p+1 given tokens <= p

@@ -68,6 +68,10 @@ SIGNATURES = {
     "pio_viecap_entity_logits": (c_int32, [c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p]),
     "pio_lm_score": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "pio_viecap_decode": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "pio_viecap_build_prompt": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "pio_lm_prefill": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "pio_lm_advance": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "pio_beam_select": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "pio_mem_topk": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "pio_text_project": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
                                    c_void_p, c_void_p, c_void_p]),

@@ -140,6 +140,7 @@ struct pio_context {
   float* bank = nullptr; float* bank_inv = nullptr; int64_t bank_rows = 0; int bank_dim = 0;
   float bank_scale = 0.f;   // > 0: the projection runs on split fp16 operands of bank * bank_scale (project.hip) ...
   float* bank_split = nullptr;   // ... [rows][2][dim] fp16 (hi plane, lo plane), the same bytes again as the fp32 bank
+  float *beam_k = nullptr, *beam_v = nullptr, *beam_stats = nullptr;   // beam search: KV gather scratch (allocated on first use), row statistics
   float *part_acc = nullptr, *part_ml = nullptr, *sims = nullptr;
   int parts = 512;   // two k_project workgroups per CU
   // device-side image transforms (pio_preprocess): growable intermediate image, a ring of table slots
@@ -1260,6 +1261,80 @@ int pio_lm_score(pio_handle c, const int32_t* tokens, const int32_t* lens, int32
   a.xh = c->dec_xh; a.lm_stats = c->lm_stats; a.lm_gmax = c->lm_gmax; a.pos_base = 0;
   HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, 64 * sizeof(unsigned), s));
   HIP_OK(launch_lm_score(a, tokens, lens, Lmax, nll, s));
+  return PIO_OK;
+}
+
+// DecoderArgs of a single-position / prompt pass over the handle's language model (no greedy loop)
+static DecoderArgs lm_args(pio_context* c, int N) {
+  DecoderArgs a;
+  a.N = N; a.steps = 1; a.E = c->cfg.dec_embd; a.heads = c->cfg.dec_heads; a.layers = c->cfg.dec_layers; a.vocab = c->cfg.dec_vocab;
+  a.prefix_size = c->cfg.prefix_size; a.eps = c->cfg.dec_ln_eps; a.prefix = nullptr; a.clip_w = nullptr; a.clip_b = nullptr;
+  a.wte = c->wte; a.wpe = c->wpe; a.head_w = c->head_w; a.head_c = c->head_c; a.head_d = c->head_d; a.layer = c->dl.data();
+  a.x = c->dx; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.splitk_ws = c->splitk_ws; a.splitk_cnt = c->splitk_cnt;
+  a.kcache = c->kcache; a.vcache = c->vcache; a.max_steps = c->cfg.max_steps; a.logits = c->logits; a.ids = c->ids_buf; a.logprob = nullptr;
+  a.head_w16 = c->head_w16; a.head_w16_unscale = c->head_w16_unscale; a.head_bound_coef = c->head_bound_coef;
+  a.xh = c->dec_xh; a.lm_stats = c->lm_stats; a.lm_gmax = c->lm_gmax; a.pos_base = 0;
+  return a;
+}
+
+static int beam_scratch(pio_context* c) {
+  if (c->beam_stats) return PIO_OK;
+  int rc;
+  const size_t kv = (size_t)c->cfg.dec_layers * c->cfg.max_prefixes * c->cfg.max_steps * c->cfg.dec_embd;
+  if ((rc = c->dmalloc(&c->beam_k, kv))) return rc;
+  if ((rc = c->dmalloc(&c->beam_v, kv))) return rc;
+  return c->dmalloc(&c->beam_stats, (size_t)2 * 16);
+}
+
+int pio_viecap_build_prompt(pio_handle c, const float* cont, const int32_t* tokens, int32_t N, int32_t Lt, int32_t soft_first,
+                            float* prompt, pio_stream stream) {
+  if (!c || !prompt || (Lt > 0 && !tokens)) return fail(PIO_ERR_INVALID_ARG, "pio_viecap_build_prompt: null argument");
+  if (!cont && Lt < 1) return fail(PIO_ERR_INVALID_ARG, "pio_viecap_build_prompt: neither a soft prompt nor prompt tokens");
+  if (!c->has_dec || (cont && !c->has_map)) return fail(PIO_ERR_NOT_READY, "pio_viecap_build_prompt: language model / mapping network not loaded");
+  if (N < 1 || Lt < 0) return fail(PIO_ERR_INVALID_ARG, "pio_viecap_build_prompt: bad shape");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  HIP_OK(launch_build_prompt(cont, tokens, c->wte, N, cont ? c->map_Lc : 0, Lt, c->cfg.dec_embd, c->cfg.dec_vocab, soft_first, prompt,
+                             (hipStream_t)stream));
+  return PIO_OK;
+}
+
+int pio_lm_prefill(pio_handle c, const float* embeds, int32_t N, int32_t P, float* logp, pio_stream stream) {
+  if (!c || !embeds || !logp) return fail(PIO_ERR_INVALID_ARG, "pio_lm_prefill: null argument");
+  if (!c->has_dec) return fail(PIO_ERR_NOT_READY, "pio_lm_prefill: language model not loaded");
+  if (N < 1 || N > 16 || N > c->cfg.max_prefixes) return fail(PIO_ERR_CAPACITY, "pio_lm_prefill: 1 <= N <= min(16, max_prefixes) rows per call");
+  if (P < 1 || P > c->cfg.max_steps || P > 256) return fail(PIO_ERR_CAPACITY, "pio_lm_prefill: P above max_steps");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  int rc;
+  if ((rc = beam_scratch(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const DecoderArgs a = lm_args(c, N);
+  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, 64 * sizeof(unsigned), s));
+  HIP_OK(launch_lm_prefill(a, embeds, P, c->beam_stats, logp, s));
+  return PIO_OK;
+}
+
+int pio_lm_advance(pio_handle c, const int32_t* tokens, const int32_t* src_rows, int32_t N, int32_t pos, float* logp, pio_stream stream) {
+  if (!c || !tokens || !logp) return fail(PIO_ERR_INVALID_ARG, "pio_lm_advance: null argument");
+  if (!c->has_dec) return fail(PIO_ERR_NOT_READY, "pio_lm_advance: language model not loaded");
+  if (N < 1 || N > 16 || N > c->cfg.max_prefixes) return fail(PIO_ERR_CAPACITY, "pio_lm_advance: 1 <= N <= min(16, max_prefixes) rows per call");
+  if (pos < 1 || pos + 1 > c->cfg.max_steps || pos + 1 > 256) return fail(PIO_ERR_CAPACITY, "pio_lm_advance: position above max_steps");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  int rc;
+  if ((rc = beam_scratch(c))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const DecoderArgs a = lm_args(c, N);
+  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, 64 * sizeof(unsigned), s));
+  HIP_OK(launch_lm_advance(a, tokens, src_rows, pos, c->beam_k, c->beam_v, c->beam_stats, logp, s));
+  return PIO_OK;
+}
+
+int pio_beam_select(pio_handle c, const float* logp, const float* scores, const float* lens, const int32_t* stopped, int32_t W,
+                    float* out_val, int64_t* out_idx, pio_stream stream) {
+  if (!c || !logp || !out_val || !out_idx || (scores && (!lens || !stopped)))
+    return fail(PIO_ERR_INVALID_ARG, "pio_beam_select: null argument");
+  if (W < 1 || W > 8) return fail(PIO_ERR_INVALID_ARG, "pio_beam_select: beam width must be 1..8");
+  HIP_OK(hipSetDevice(c->cfg.device));
+  HIP_OK(launch_beam_select(logp, scores, lens, stopped, W, c->cfg.dec_vocab, out_val, out_idx, (hipStream_t)stream));
   return PIO_OK;
 }
 

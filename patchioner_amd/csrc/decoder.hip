@@ -1535,4 +1535,180 @@ hipError_t launch_decode_prompted(const DecoderArgs& a, const float* prompt, int
   return hipGetLastError();
 }
 
+// ---- beam search building blocks (ViECap: P/src/viecap/search.py:193-285; entrypoint.py:143-148 calls it per image with
+// beam_width beams).  The reference re-runs the whole sequence of every beam each step; here the beams keep KV caches that are
+// re-gathered by source beam after every selection.  None of this is on the benchmarked path: plain kernels.
+// x[n][:] = wte[tokens[n]][:] + wpe[pos][:]
+__global__ __launch_bounds__(256) void k_dec_token1_x(const int32_t* __restrict__ tokens, int pos, const float* __restrict__ wte,
+                                                      const float* __restrict__ wpe, int E, int V, float* x) {
+  const int n = blockIdx.x;
+  int t = tokens[n];
+  t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+  for (int d = threadIdx.x; d < E; d += 256) x[(size_t)n * E + d] = wte[(size_t)t * E + d] + wpe[(size_t)pos * E + d];
+}
+
+// dst[l][n][p][:] = src[l][rows ? rows[n] : n][p][:] for p < npos; grid (npos, N, layers)
+__global__ __launch_bounds__(192) void k_kv_gather(const float* __restrict__ src, float* __restrict__ dst, const int32_t* __restrict__ rows,
+                                                   int N, int max_steps, int E) {
+  const int p = blockIdx.x, n = blockIdx.y, l = blockIdx.z;
+  int r = rows ? rows[n] : n;
+  r = r < 0 ? 0 : (r >= N ? N - 1 : r);
+  const float4* a = (const float4*)(src + (((size_t)l * N + r) * max_steps + p) * E);
+  float4* b = (float4*)(dst + (((size_t)l * N + n) * max_steps + p) * E);
+  for (int d = threadIdx.x; d < E / 4; d += 192) b[d] = a[d];
+}
+
+// mean and 1 / sqrt(var + eps) of every row of x (the final LayerNorm the LM head folds in)
+__global__ __launch_bounds__(256) void k_row_stats(const float* __restrict__ x, int E, float eps, float* stats) {
+  __shared__ float s_a[4], s_b[4];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  float sx = 0.f, sq = 0.f;
+  for (int d = tid; d < E; d += 256) { const float v = x[(size_t)n * E + d]; sx += v; sq += v * v; }
+  sx = wave_sum(sx); sq = wave_sum(sq);
+  if ((tid & 63) == 0) { s_a[tid >> 6] = sx; s_b[tid >> 6] = sq; }
+  __syncthreads();
+  if (tid == 0) {
+    const float tx = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]), tq = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
+    const float mu = tx / (float)E, var = fmaxf(tq / (float)E - mu * mu, 0.f);
+    stats[2 * n] = mu;
+    stats[2 * n + 1] = rsqrtf(var + eps);
+  }
+}
+
+// every logit of every row: out[n][v] = rstd_n (<x_n, W'_v> - mu_n c_v) + d_v (the LayerNorm-folded tied head, fp32); one wave per column
+__global__ __launch_bounds__(256) void k_lm_logits_full(const float* __restrict__ W, const float* __restrict__ X, int N, int V, int E,
+                                                        const float* __restrict__ dvec, const float* __restrict__ cvec,
+                                                        const float* __restrict__ stats, float* out) {
+  const int lane = threadIdx.x & 63;
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= V) return;
+  const float* w = W + (size_t)v * E;
+  for (int n = 0; n < N; ++n) {
+    float acc = 0.f;
+    for (int d = lane; d < E; d += 64) acc = fmaf(X[(size_t)n * E + d], w[d], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) out[(size_t)n * V + v] = stats[2 * n + 1] * (acc - stats[2 * n] * cvec[v]) + dvec[v];
+  }
+}
+
+// in place: row -> log(softmax(row)) evaluated as the reference does (search.py:246: logits.softmax(-1).log())
+__global__ __launch_bounds__(1024) void k_log_softmax_rows(float* x, int V) {
+  __shared__ float red[16];
+  float* r = x + (size_t)blockIdx.x * V;
+  const int tid = threadIdx.x;
+  float m = -INFINITY;
+  for (int v = tid; v < V; v += 1024) m = fmaxf(m, r[v]);
+  m = wave_max(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = red[0];
+  for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+  __syncthreads();
+  float s = 0.f;
+  for (int v = tid; v < V; v += 1024) s += expf(r[v] - m);
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  s = 0.f;
+  for (int i = 0; i < 16; ++i) s += red[i];
+  for (int v = tid; v < V; v += 1024) r[v] = logf(expf(r[v] - m) / s);
+}
+
+// One selection of beam_search (search.py:247-266).  Candidate (b, v):
+//   first step (scores == null): lp[0][v], row 0 only (scores, next_tokens = logits.topk(beam_width));
+//   later: stopped[b] ? (v == 0 ? scores[b] / lens[b] : -inf) : (scores[b] + lp[b][v]) / (lens[b] + 1)
+// (logits[is_stopped] = -inf, logits[is_stopped, 0] = 0; seq_lengths[~is_stopped] += 1; the sum divided by the length).  The W largest,
+// descending, ties to the lower flat index b V + v -> out_val[W], out_idx[W].  One workgroup; W <= 8.
+__global__ __launch_bounds__(1024) void k_beam_select(const float* __restrict__ lp, const float* __restrict__ scores,
+                                                      const float* __restrict__ lens, const int32_t* __restrict__ stopped, int W, int V,
+                                                      float* out_val, int64_t* out_idx) {
+  __shared__ float s_v[16];
+  __shared__ long long s_i[16];
+  __shared__ int s_win;
+  const int tid = threadIdx.x;
+  float bv[8];
+  long long bi[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { bv[k] = -INFINITY; bi[k] = -1; }
+  const int rows = scores ? W : 1;
+  const long long total = (long long)rows * V;
+  for (long long c = tid; c < total; c += 1024) {
+    const int b = (int)(c / V), v = (int)(c - (long long)b * V);
+    float val;
+    if (!scores) val = lp[v];
+    else if (stopped[b]) val = v == 0 ? scores[b] / lens[b] : -INFINITY;
+    else val = (scores[b] + lp[(size_t)b * V + v]) / (lens[b] + 1.0f);
+    if (!(val > bv[7]) && bi[7] >= 0) continue;        // not better than this thread's worst kept candidate (NaN never enters)
+    if (!(val == val)) continue;
+    // insert (val, c) into the thread's descending list; equal values keep the earlier (lower) index first
+    int k = 7;
+    while (k > 0 && (bi[k - 1] < 0 || val > bv[k - 1])) { bv[k] = bv[k - 1]; bi[k] = bi[k - 1]; --k; }
+    bv[k] = val; bi[k] = c;
+  }
+  int head = 0;
+  for (int round = 0; round < W; ++round) {
+    float v = head < 8 ? bv[head] : -INFINITY;
+    long long i = head < 8 ? bi[head] : -1;
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o);
+      const long long oi = __shfl_xor(i, o);
+      if (oi >= 0 && (i < 0 || ov > v || (ov == v && oi < i))) { v = ov; i = oi; }
+    }
+    if ((tid & 63) == 0) { s_v[tid >> 6] = v; s_i[tid >> 6] = i; }
+    __syncthreads();
+    if (tid == 0) {
+      float fv = s_v[0]; long long fi = s_i[0];
+      for (int w = 1; w < 16; ++w)
+        if (s_i[w] >= 0 && (fi < 0 || s_v[w] > fv || (s_v[w] == fv && s_i[w] < fi))) { fv = s_v[w]; fi = s_i[w]; }
+      out_val[round] = fv;
+      out_idx[round] = fi;
+      s_win = fi >= 0 ? (int)(fi % 1024) : -1;       // the thread that owns candidate fi (c = tid + 1024 j)
+    }
+    __syncthreads();
+    if (tid == s_win) ++head;
+    __syncthreads();
+  }
+}
+
+static hipError_t lm_logp_rows(const DecoderArgs& a, float* stats, float* logp, hipStream_t s) {
+  hipLaunchKernelGGL(k_row_stats, dim3(a.N), dim3(256), 0, s, a.x, a.E, a.eps, stats);
+  hipLaunchKernelGGL(k_lm_logits_full, dim3(ceil_div(a.vocab, 4)), dim3(256), 0, s, a.head_w, a.x, a.N, a.vocab, a.E, a.head_d, a.head_c,
+                     stats, logp);
+  hipLaunchKernelGGL(k_log_softmax_rows, dim3(a.N), dim3(1024), 0, s, logp, a.vocab);
+  return hipGetLastError();
+}
+
+// embeds [N][P][E] at positions 0..P-1 -> logp [N][V] = log softmax of the logits of position P-1
+hipError_t launch_lm_prefill(const DecoderArgs& a, const float* embeds, int P, float* stats, float* logp, hipStream_t s) {
+  if (P < 1 || a.N < 1 || a.N > 16 || !dec_args_ok(a, false, P)) return hipErrorInvalidValue;
+  for (int pos = 0; pos < P; ++pos) {
+    hipLaunchKernelGGL(k_dec_prompt_x, dim3(a.N), dim3(256), 0, s, embeds, a.wpe, P, pos, a.E, a.x);
+    PIO_TRY(dec_layers_step(a, pos, s));
+  }
+  return lm_logp_rows(a, stats, logp, s);
+}
+
+// beams re-ordered (KV rows of positions < pos gathered by src_rows through kv_scratch), then token[n] at position pos -> logp [N][V]
+hipError_t launch_lm_advance(const DecoderArgs& a, const int32_t* tokens, const int32_t* src_rows, int pos, float* kscratch,
+                             float* vscratch, float* stats, float* logp, hipStream_t s) {
+  if (pos < 1 || a.N < 1 || a.N > 16 || !dec_args_ok(a, false, pos + 1)) return hipErrorInvalidValue;
+  if (src_rows) {
+    const dim3 g(pos, a.N, a.layers);
+    hipLaunchKernelGGL(k_kv_gather, g, dim3(192), 0, s, a.kcache, kscratch, src_rows, a.N, a.max_steps, a.E);
+    hipLaunchKernelGGL(k_kv_gather, g, dim3(192), 0, s, a.vcache, vscratch, src_rows, a.N, a.max_steps, a.E);
+    hipLaunchKernelGGL(k_kv_gather, g, dim3(192), 0, s, kscratch, a.kcache, (const int32_t*)nullptr, a.N, a.max_steps, a.E);
+    hipLaunchKernelGGL(k_kv_gather, g, dim3(192), 0, s, vscratch, a.vcache, (const int32_t*)nullptr, a.N, a.max_steps, a.E);
+  }
+  hipLaunchKernelGGL(k_dec_token1_x, dim3(a.N), dim3(256), 0, s, tokens, pos, a.wte, a.wpe, a.E, a.vocab, a.x);
+  PIO_TRY(dec_layers_step(a, pos, s));
+  return lm_logp_rows(a, stats, logp, s);
+}
+
+hipError_t launch_beam_select(const float* logp, const float* scores, const float* lens, const int32_t* stopped, int W, int V,
+                              float* out_val, int64_t* out_idx, hipStream_t s) {
+  if (W < 1 || W > 8 || V < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_beam_select, dim3(1), dim3(1024), 0, s, logp, scores, lens, stopped, W, V, out_val, out_idx);
+  return hipGetLastError();
+}
+
 }  // namespace pio

@@ -170,6 +170,12 @@ hipError_t launch_decode_greedy(const DecoderArgs& a, hipStream_t s);
 hipError_t launch_decode_prompted(const DecoderArgs& a, const float* prompt, int P, hipStream_t s);
 // teacher-forced pass over given tokens [N][Lmax] (rows of lens[n] tokens): nll[n] = sum over p + 1 < lens[n] of -log p(token p+1 | tokens <= p); N <= 64
 hipError_t launch_lm_score(const DecoderArgs& a, const int32_t* tokens, const int32_t* lens, int Lmax, float* nll, hipStream_t s);
+// beam search building blocks (N <= 16 beams per call; stats: [N][2] scratch; logp [N][V] = log softmax of the next-token logits)
+hipError_t launch_lm_prefill(const DecoderArgs& a, const float* embeds, int P, float* stats, float* logp, hipStream_t s);
+hipError_t launch_lm_advance(const DecoderArgs& a, const int32_t* tokens, const int32_t* src_rows, int pos, float* kscratch,
+                             float* vscratch, float* stats, float* logp, hipStream_t s);
+hipError_t launch_beam_select(const float* logp, const float* scores, const float* lens, const int32_t* stopped, int W, int V,
+                              float* out_val, int64_t* out_idx, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // ViECap head (viecap.hip): mapping network, entity logits, prompt assembly -- all fp32

@@ -95,7 +95,10 @@ def _id_columns(model) -> int:
     steps for the DeCap / CapDec decoder (decap.py:116), 64 for the ViECap greedy search (search.py:108-191)."""
     if getattr(model, "calculate_argmax_text", False):
         raise ValueError("sharded captioning gathers token ids; a calculate_argmax_text model returns bank texts and has none")
-    return 64 if getattr(model, "viecap", None) is not None else 30
+    head = getattr(model, "viecap", None)
+    if head is not None and not getattr(getattr(head, "args", None), "using_greedy_search", True):
+        raise ValueError("sharded captioning gathers the greedy search's token ids; a beam-search ViECap head returns sentences only")
+    return 64 if head is not None else 30
 
 
 def _last_ids(model, steps: int) -> torch.Tensor:

@@ -418,6 +418,50 @@ class Engine:
                                              e - s, Lt, 1 if soft_first else 0, int(steps), ptr(ids[s:e]), _stream()))
         return ids
 
+    def viecap_build_prompt(self, cont: Optional[torch.Tensor], tokens: Optional[torch.Tensor], soft_first: bool = True) -> torch.Tensor:
+        """The prompt embeddings [N, Lc + Lt, E] as viecap_decode assembles them (word_embed + torch.cat, entrypoint.py:126-135)."""
+        tok = self._dev(tokens, torch.int32) if tokens is not None else None
+        if cont is None and tok is None:
+            raise ValueError("viecap_build_prompt: neither a soft prompt nor prompt tokens")
+        N = cont.shape[0] if cont is not None else tok.shape[0]
+        Lt = int(tok.shape[1]) if tok is not None else 0
+        Lc = int(cont.shape[1]) if cont is not None else 0
+        out = torch.empty(N, Lc + Lt, self.cfg.dec_embd, device=self.device, dtype=torch.float32)
+        check(self.lib.pio_viecap_build_prompt(self.h, ptr(cont.contiguous()) if cont is not None else None,
+                                               ptr(tok) if tok is not None else None, N, Lt, 1 if soft_first else 0, ptr(out), _stream()))
+        return out
+
+    # ---- beam search building blocks (search.py:193-285): the W beams of ONE image are the rows of these calls
+    def lm_prefill(self, embeds: torch.Tensor) -> torch.Tensor:
+        """embeds [W, P, E] (the prompt, once per beam) -> log(softmax(next-token logits)) [W, vocab]."""
+        embeds = self._dev(embeds).contiguous()
+        W, P = int(embeds.shape[0]), int(embeds.shape[1])
+        logp = torch.empty(W, self.cfg.dec_vocab, device=self.device, dtype=torch.float32)
+        check(self.lib.pio_lm_prefill(self.h, ptr(embeds), W, P, ptr(logp), _stream()))
+        return logp
+
+    def lm_advance(self, tokens: torch.Tensor, src_rows: Optional[torch.Tensor], pos: int) -> torch.Tensor:
+        """Row n continues the sequence of row src_rows[n] (None: as they are) with tokens[n] at position ``pos`` -> log-probabilities."""
+        tok = self._dev(tokens, torch.int32).contiguous()
+        src = self._dev(src_rows, torch.int32).contiguous() if src_rows is not None else None
+        W = int(tok.shape[0])
+        logp = torch.empty(W, self.cfg.dec_vocab, device=self.device, dtype=torch.float32)
+        check(self.lib.pio_lm_advance(self.h, ptr(tok), ptr(src) if src is not None else None, W, int(pos), ptr(logp), _stream()))
+        return logp
+
+    def beam_select(self, logp: torch.Tensor, scores=None, lens=None, stopped=None):
+        """One selection of beam_search (see pio_beam_select) -> (values [W] fp32, flat indices [W] int64), on the host."""
+        W = int(logp.shape[0])
+        val = torch.empty(W, device=self.device, dtype=torch.float32)
+        idx = torch.empty(W, device=self.device, dtype=torch.int64)
+        if scores is None:
+            check(self.lib.pio_beam_select(self.h, ptr(logp), None, None, None, W, ptr(val), ptr(idx), _stream()))
+        else:
+            sc, ln = self._dev(scores, torch.float32).contiguous(), self._dev(lens, torch.float32).contiguous()
+            st = self._dev(stopped, torch.int32).contiguous()
+            check(self.lib.pio_beam_select(self.h, ptr(logp), ptr(sc), ptr(ln), ptr(st), W, ptr(val), ptr(idx), _stream()))
+        return val.cpu(), idx.cpu()
+
     # ------------------------------------------------------------------ a11/a12 decoder
     def decode_greedy(self, prefix: torch.Tensor, steps: int = 30, want_logprob: bool = False):
         prefix = self._dev(prefix)

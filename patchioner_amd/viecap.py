@@ -213,9 +213,8 @@ class VieCapHead:
         self.clip_hidden_size = args_dict.get("clip_hidden_size") or (640 if "RN" in (clip_name or "") else 512)
         if "gpt" not in a.language_model:
             raise NotImplementedError("ViECap with an OPT language model (opt_search): outside the hot-path scope")
-        if not a.using_greedy_search:
-            raise NotImplementedError("ViECap beam search (search.py:193-285): the hot path is the greedy search the shipped "
-                                      "config selects (using_greedy_search: True)")
+        if not a.using_greedy_search and not 1 <= int(a.beam_width) <= 8:
+            raise ValueError("viecap.beam_width must be 1..8 (pio_beam_select)")
         if args_dict.get("entities_text") is not None:
             self.entities_text = list(args_dict["entities_text"])
             emb = torch.as_tensor(args_dict["texts_embeddings"]).float()
@@ -261,7 +260,16 @@ class VieCapHead:
             self.last_prompt_tokens = tokens
         if a.using_hard_prompt and a.only_hard_prompt:
             cont = None                                                  # entrypoint.py:130-131: the word embeddings alone
-        ids = eng.viecap_decode(cont, tokens, soft_first=bool(a.soft_prompt_first) or tokens is None, steps=64)
+        soft_first = bool(a.soft_prompt_first) or tokens is None
+        if not a.using_greedy_search:
+            # entrypoint.py:143-148: one beam_search call per element of the batch, the best beam's sentence of each
+            prompts = eng.viecap_build_prompt(cont, tokens, soft_first=soft_first)
+            out = [self.beam_search(prompts[i:i + 1], int(a.beam_width))[0] for i in range(N)]
+            self.last_ids = None                  # no [N, 64] id tensor: the beams of an image have their own lengths
+            if compute_scores:
+                return out, self.compute_perplexity(out)
+            return out
+        ids = eng.viecap_decode(cont, tokens, soft_first=soft_first, steps=64)
         self.last_ids = ids
         rows = ids.cpu().tolist()
         if N == 1:
@@ -284,6 +292,49 @@ class VieCapHead:
         if compute_scores:
             return out, self.compute_perplexity(out)
         return out
+
+    def beam_search(self, embeddings: torch.Tensor, beam_width: int = 5, max_len: int = 64, end_of_sentences=(".", " .")) -> List[str]:
+        """``beam_search`` (search.py:193-285) for ONE prompt [1, P, E]: every beam's sentence, best first.  The language model and
+        each selection run on the device (Engine.lm_prefill / lm_advance / beam_select, beams = rows with their own KV caches);
+        what is left here is the reference's bookkeeping -- token lists, lengths, stop flags, fp32 score arithmetic -- line by line.
+        ``self.last_beams``: (token ids, length, score) per beam in the order of the last selection."""
+        import numpy as np
+        eng = self.engine
+        W = int(beam_width)
+        P = int(embeddings.shape[1])
+        V = eng.cfg.dec_vocab
+        eos = [self.tokenizer.encode(e)[-1] for e in end_of_sentences]
+        assert len(eos) == 2                                                    # search.py:276
+        lp = eng.lm_prefill(embeddings.expand(W, -1, -1).contiguous())          # the prompt, once per beam
+        val, idx = eng.beam_select(lp)                                          # :247-249: scores, next_tokens = logits.topk(W)
+        scores = val.numpy().astype(np.float32)
+        next_tokens = idx.numpy().astype(np.int64)
+        tokens = [[int(t)] for t in next_tokens]
+        seq_lengths = np.ones(W, dtype=np.float32)
+        is_stopped = np.zeros(W, dtype=bool)
+        is_stopped = is_stopped | (next_tokens == eos[0]) | (next_tokens == eos[1])
+        src = None
+        for i in range(1, max_len):
+            if is_stopped.all():
+                break
+            lp = eng.lm_advance(torch.from_numpy(next_tokens.astype(np.int32)), None if src is None else torch.from_numpy(src.astype(np.int32)),
+                                pos=P + i - 1)
+            val, idx = eng.beam_select(lp, torch.from_numpy(scores), torch.from_numpy(seq_lengths), torch.from_numpy(is_stopped.astype(np.int32)))
+            seq_lengths[~is_stopped] += 1                                       # :257
+            avg, flat = val.numpy().astype(np.float32), idx.numpy().astype(np.int64)
+            src = flat // V                                                     # :261 next_tokens_source
+            seq_lengths = seq_lengths[src]
+            next_tokens = flat % V
+            tokens = [tokens[int(b)] + [int(t)] for b, t in zip(src, next_tokens)]
+            scores = (avg * seq_lengths).astype(np.float32)                     # :269
+            is_stopped = is_stopped[src]
+            is_stopped = is_stopped | (next_tokens == eos[0]) | (next_tokens == eos[1])
+        scores = (scores / seq_lengths).astype(np.float32)
+        texts = [self.tokenizer.decode(t[:int(n)]) for t, n in zip(tokens, seq_lengths)]
+        order = torch.from_numpy(scores).argsort(descending=True).tolist()
+        self.last_beams = [(tokens[b][:int(seq_lengths[b])], float(seq_lengths[b]), float(scores[b])) for b in range(W)]
+        self.last_beam_order = order
+        return [texts[b] for b in order]
 
     def compute_perplexity(self, sentences) -> List[float]:
         """entrypoint.py:155-172: every caption is tokenised again and scored by the language model with labels = inputs:

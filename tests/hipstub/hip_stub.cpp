@@ -79,6 +79,9 @@ hipError_t launch_revert(const float*, const float*, const float*, int, int, int
 hipError_t launch_decode_greedy(const DecoderArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_decode_prompted(const DecoderArgs&, const float*, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_lm_score(const DecoderArgs&, const int32_t*, const int32_t*, int, float*, hipStream_t) { return hipSuccess; }
+hipError_t launch_lm_prefill(const DecoderArgs&, const float*, int, float*, float*, hipStream_t) { return hipSuccess; }
+hipError_t launch_lm_advance(const DecoderArgs&, const int32_t*, const int32_t*, int, float*, float*, float*, float*, hipStream_t) { return hipSuccess; }
+hipError_t launch_beam_select(const float*, const float*, const float*, const int32_t*, int, int, float*, int64_t*, hipStream_t) { return hipSuccess; }
 hipError_t launch_viecap_mapping(const ViecapMapArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_sgemm_tn(const float*, int, const float*, int, const float*, float, float*, int, int, int, int, int, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_build_prompt(const float*, const int32_t*, const float*, int, int, int, int, int, int, float*, hipStream_t) { return hipSuccess; }

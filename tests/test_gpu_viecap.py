@@ -163,6 +163,54 @@ def test_viecap_only_hard_prompt_vs_the_oracle(O, case):
         m.engine.viecap_decode(None, None)
 
 
+def test_viecap_beam_search_vs_reference_and_oracle(O, golden, case):
+    """using_greedy_search False: VieCap.forward calls beam_search per image (entrypoint.py:143-148, search.py:193-285).  The beams
+    of the HIP path (pio_lm_prefill / pio_lm_advance / pio_beam_select + the reference's bookkeeping in viecap.py) against the
+    REFERENCE's (tests/golden/viecap_beam.npz): every beam's ids and the returned order, for the reference's own end-of-sentence
+    strings and for two the seeded model emits (beams stop at different steps).  A departure must sit at a selection whose
+    margin (last chosen vs first rejected candidate, from the oracle) is inside the parity bound."""
+    g = golden("viecap_beam")
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    w, tok, ents, emb, x = case
+    c = gc.VIECAP
+    m = _model(_viecap_cfg(w, tok, ents, emb, c["C"], using_greedy_search=False, beam_width=5))
+    orc = O.ViECapOracle(w, tok, ents, emb, temperature=c["temperature"], top_k=c["top_k"], threshold=c["threshold"],
+                         using_hard_prompt=True, soft_prompt_first=True)
+    prompts_ref = orc.prompt_embeddings(x[:3].clone())
+    head = m.viecap
+    xd = x[:3].clone().cuda()
+    cont = m.engine.viecap_mapping(xd)
+    # the prompt tokens as forward() builds them
+    head.forward(x[:1].clone())                 # also exercises the routing: one beam search, a list with one sentence
+    probs = m.engine.viecap_entity_logits(xd, c["temperature"]).cpu()
+    rows = [tok.encode(V.compose_discrete_prompt_text(V.top_k_entities(ents, probs[i], c["top_k"], c["threshold"]))) for i in range(3)]
+    L = max(len(r) for r in rows)
+    pad = tok.pad_token_id if tok.pad_token_id is not None else 0
+    tokens = torch.full((3, L), pad, dtype=torch.int32)
+    for i, r in enumerate(rows):
+        tokens[i, :len(r)] = torch.tensor(r, dtype=torch.int32)
+    prompts = m.engine.viecap_build_prompt(cont, tokens, soft_first=True)
+    np.testing.assert_allclose(prompts.cpu().numpy(), prompts_ref.numpy(), rtol=1e-4, atol=2e-5)
+    exact = 0
+    for call in meta["calls"]:
+        eos = (".", " .") if call["label"] == "default" else tuple(meta["eos_strings"])
+        i = call["image"]
+        got = head.beam_search(prompts[i:i + 1], 5, end_of_sentences=eos)
+        ref = g["%s_%d_ids" % (call["label"], i)]
+        same = all(head.last_beams[b][0] == ref[b, :int((ref[b] >= 0).sum())].tolist() for b in range(5))
+        if same:
+            assert got == call["sentences"], (call["label"], i)
+            exact += 1
+        else:
+            orc.beam_search(prompts_ref[i:i + 1], beam_width=5, end_of_sentences=eos)
+            worst = min(orc.last_beam["margins"])
+            assert worst <= MARGIN_BOUND, "%s image %d: beams differ although every selection margin is >= %.2e" % (call["label"], i, worst)
+    print("beam search: %d / %d calls identical to the reference (ids of all 5 beams and the order returned)" % (exact, len(meta["calls"])))
+    assert exact >= len(meta["calls"]) - 1
+    out = m.caption_tokens(x[:2].clone().cuda())
+    assert isinstance(out, list) and len(out) == 2 and all(isinstance(s, str) for s in out)
+
+
 def test_config5_shape_vitl14_fp16_attention_weighted_traces(O):
     """BASELINE config 5 on one GPU's shard: ViT-L/14 (D = 1024, 2 of its 24 blocks here), fp16 operands, 16 images,
     attention-weighted trace regions into the ViECap head (clip_hidden_size 1024, entity matrix [K, 1024]): the decoder

@@ -49,6 +49,31 @@ def test_oracle_matches_the_reference_pieces(golden, case):
     assert np.isnan(orc.compute_perplexity(["c"])[0]) if len(tok.encode("c")) == 1 else True      # one token: mean of nothing
 
 
+def test_oracle_beam_search_matches_the_reference(golden, case):
+    """tests/golden/viecap_beam.npz: the reference's beam_search (search.py:193-285) on three prompts, with its own end-of-sentence
+    strings and with two the seeded model does emit (beams stop at different steps): every beam's ids and the returned order."""
+    g = golden("viecap_beam")
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    w, tok, ents, emb, x = case
+    c = gc.VIECAP
+    orc = O.ViECapOracle(w, tok, ents, emb, temperature=c["temperature"], top_k=c["top_k"], threshold=c["threshold"],
+                         using_hard_prompt=True, soft_prompt_first=True)
+    prompts = orc.prompt_embeddings(x[:3].clone())
+    stops = 0
+    for call in meta["calls"]:
+        eos = (".", " .") if call["label"] == "default" else tuple(meta["eos_strings"])
+        i = call["image"]
+        got = orc.beam_search(prompts[i:i + 1], beam_width=5, end_of_sentences=eos)
+        ref = g["%s_%d_ids" % (call["label"], i)]
+        worst = min(orc.last_beam["margins"])
+        for b in range(5):
+            n = int((ref[b] >= 0).sum())
+            assert orc.last_beam["ids"][b] == ref[b, :n].tolist(), (call["label"], i, b, "smallest selection margin %.2e" % worst)
+        assert got == call["sentences"], (call["label"], i)
+        stops += sum(l < 64 for l in call["lengths"])
+    assert stops >= 5, "the fixture should exercise beams that stop early"
+
+
 def test_mirror_host_logic_matches_the_oracle(case):
     w, tok, ents, emb, x = case
     assert V.compose_discrete_prompt_text([]) == O.ViECapOracle.prompt_text([]) == "There are something in image."
@@ -75,8 +100,9 @@ def test_config_errors_are_loud(case):
 
     base = dict(clip_hidden_size=768, entities_text=ents, texts_embeddings=emb, tokenizer=tok, using_greedy_search=True)
     V.VieCapHead(dict(base), FakeEngine(), "ViT-B/16")
-    with pytest.raises(NotImplementedError):
-        V.VieCapHead(dict(base, using_greedy_search=False), FakeEngine(), "ViT-B/16")            # beam search
+    V.VieCapHead(dict(base, using_greedy_search=False), FakeEngine(), "ViT-B/16")                # beam search (width 5)
+    with pytest.raises(ValueError):
+        V.VieCapHead(dict(base, using_greedy_search=False, beam_width=9), FakeEngine(), "ViT-B/16")
     with pytest.raises(NotImplementedError):
         V.VieCapHead(dict(base, language_model="facebook/opt-1.3b"), FakeEngine(), "ViT-B/16")
     with pytest.raises(FileNotFoundError):
