@@ -146,29 +146,11 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm256(const GemmArgs g) {
       fa[rt][s] = *(const frag_t*)(smem + half_off(0, (buf), (i)) + rt * 4096 + a_rd + co[s])
 #define G256_READ_B(dst, buf, j)                                                                         \
   _Pragma("unroll") for (int s = 0; s < 4; ++s) dst[s] = *(const frag_t*)(smem + half_off(0, (buf), (j)) + b_rd + co[s])
-#if PIO_G256_MFMA16_TIMING      // TIMING EXPERIMENT ONLY (results are not a GEMM): the same operand reads, registers and FLOPs issued as
-                                // v_mfma_f32_16x16x32 blocks, to see which clock the chip holds on that shape
-#define G256_SUB16(q, A_, B_)                                                                            \
-  do {                                                                                                   \
-    f32x4 _c = {acc[i_][j_][rt][4 * q], acc[i_][j_][rt][4 * q + 1], acc[i_][j_][rt][4 * q + 2], acc[i_][j_][rt][4 * q + 3]}; \
-    _c = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_, B_, _c, 0, 0, 0);                                    \
-    acc[i_][j_][rt][4 * q] = _c[0]; acc[i_][j_][rt][4 * q + 1] = _c[1]; acc[i_][j_][rt][4 * q + 2] = _c[2]; acc[i_][j_][rt][4 * q + 3] = _c[3]; \
-  } while (0)
-#define G256_MMA(i, j, fb)                                                                               \
-  do {                                                                                                   \
-    constexpr int i_ = i, j_ = j;                                                                        \
-    _Pragma("unroll") for (int s = 0; s < 4; s += 2) _Pragma("unroll") for (int rt = 0; rt < 2; ++rt) { \
-      G256_SUB16(0, fb[s], fa[rt][s]); G256_SUB16(1, fb[s + 1], fa[rt][s]);                              \
-      G256_SUB16(2, fb[s], fa[rt][s + 1]); G256_SUB16(3, fb[s + 1], fa[rt][s + 1]);                      \
-    }                                                                                                    \
-  } while (0)
-#else
 #define G256_MMA(i, j, fb)                                                                               \
   do {                                                                                                   \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)      \
         acc[i][j][rt] = SWAP ? mfma32(fb[s], fa[rt][s], acc[i][j][rt]) : mfma32(fa[rt][s], fb[s], acc[i][j][rt]); \
   } while (0)
-#endif
 
   // ------------------------------------------------------------------------------------------------------------
   // ONE barrier per phase, the two groups run DIFFERENT programs between two barriers ("interval" k):
