@@ -262,19 +262,22 @@ def test_projection_full_bank_properties(O):
         e.close()
 
 
+@pytest.mark.parametrize("form", ["split", "exact"])
 @pytest.mark.parametrize("D,M", [(768, 100003), (768, 2049), (768, 31), (384, 40000), (512, 20011)])
-def test_projection_ragged_shapes_vs_oracle(O, D, M):
-    """k_project2 against the oracle's line-by-line restatement of Im2TxtProjector.project (im2txtprojection.py:367-385) at the
-    awkward shapes: 16- and 32-query passes, ragged query counts, banks that end inside a tile / a slab / hold fewer rows than
-    there are workgroups, a zero row (dropped at load), every bank width; and the same bits when a call is repeated.  (Rounds
-    1-2 held this kernel bit-identical to round 1's k_project on these shapes; that kernel now lives in tools/microbench/attic.)"""
+def test_projection_ragged_shapes_vs_oracle(O, D, M, form):
+    """k_project2, both forms -- split fp16 operands (the default) and exact fp32 (what the fp32 parity mode takes) -- against the
+    oracle's line-by-line restatement of Im2TxtProjector.project (im2txtprojection.py:367-385) at the awkward shapes: 16- and
+    32-query passes, ragged query counts, banks that end inside a tile / a slab / hold fewer rows than there are workgroups, a
+    zero row (dropped at load), every bank width, rows of very different magnitude; and the same bits when a call is repeated."""
     from patchioner_amd.engine import Engine
     dims = {768: (768, 12), 384: (384, 6), 512: (768, 12)}[D]
-    e = Engine(embed_dim=dims[0], depth=1, num_heads=dims[1], num_registers=4, crop_dim=224, max_batch=1, max_prefixes=128)
+    e = Engine(embed_dim=dims[0], depth=1, num_heads=dims[1], num_registers=4, crop_dim=224, max_batch=1, max_prefixes=128,
+               vit_dtype="fp32" if form == "exact" else "fp16")
     try:
         g = torch.Generator().manual_seed(M)
         bank = torch.randn(M, D, generator=g)
         bank[::97] *= 3.0
+        bank[3::101] *= 1e-3                 # rows far below the largest magnitude: their lo halves sit low in fp16's range
         if M > 100:
             bank[5] = 0
         e.set_memory_bank(bank)
