@@ -53,6 +53,9 @@ namespace pio {
 #ifndef PIO_LMF16_WAVES8      // waves per workgroup of k_lmhead_f16 at 128 prefixes (4 = round 1)
 #define PIO_LMF16_WAVES8 8
 #endif
+#ifndef PIO_LMF16_WAVES4      // ... at 33..64 prefixes
+#define PIO_LMF16_WAVES4 4
+#endif
 #ifndef PIO_LMF16_ABL         // timing ablations of k_lmhead_f16 (diagnostic builds only): 1 no epilogue, 2 no X~ DMA, 3 no MFMA
 #define PIO_LMF16_ABL 0
 #endif
@@ -1332,7 +1335,7 @@ template <int RG>
 static hipError_t launch_lmhead_f16(const DecoderArgs& a, hipStream_t s) {
   // 128 prefixes (RG = 8): 8 waves = 128 columns per workgroup share an X~ chunk, halving the X~ reads through L2 (77 instead of
   // 154 MB per step); fewer row groups keep 4 waves (two workgroups per CU cover each other's chunk waits)
-  constexpr int NWV = RG >= 8 ? PIO_LMF16_WAVES8 : 4;
+  constexpr int NWV = RG >= 8 ? PIO_LMF16_WAVES8 : (RG >= 4 ? PIO_LMF16_WAVES4 : 4);
   const int Vp = round_up(a.vocab, 64);
   const int smem = (PIO_LMF16_DEEP != 0 && RG >= 4 ? 4 : 2) * RG * 16 * 64 * 2;
   const int NGp = round_up(ceil_div(a.vocab, 16), 64);
