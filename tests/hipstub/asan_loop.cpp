@@ -143,6 +143,27 @@ int main() {
     CK(pio_viecap_decode(v, cont.data(), toks.data(), 2, 4, 1, 64, vids.data(), nullptr));
     CK(pio_viecap_decode(v, cont.data(), nullptr, 2, 0, 1, 64, vids.data(), nullptr));
     EXPECT_FAIL(pio_viecap_decode(v, cont.data(), toks.data(), 4, 100, 1, 64, vids.data(), nullptr));   // positions above max_steps
+    CK(pio_viecap_decode(v, nullptr, toks.data(), 2, 4, 0, 64, vids.data(), nullptr));                  // only_hard_prompt
+    EXPECT_FAIL(pio_viecap_decode(v, nullptr, nullptr, 2, 0, 1, 64, vids.data(), nullptr));             // neither kind of prompt
+    // beam search building blocks: prompt assembly, prefill, re-ordered advance, selection
+    {
+      const int vocab = 64;                       // dec_vocab of this configuration; max_prefixes = 4 beams
+      std::vector<float> prompt(4 * 9 * 768), logp((size_t)4 * vocab), sc(4, -1.f), ln(4, 1.f), val(4);
+      std::vector<int32_t> nt(4, 7), src{0, 0, 1, 3}, st(4, 0);
+      std::vector<int64_t> idx(4);
+      CK(pio_viecap_build_prompt(v, cont.data(), toks.data(), 4, 6, 1, prompt.data(), nullptr));
+      CK(pio_viecap_build_prompt(v, nullptr, toks.data(), 4, 6, 0, prompt.data(), nullptr));
+      EXPECT_FAIL(pio_viecap_build_prompt(v, nullptr, nullptr, 4, 0, 0, prompt.data(), nullptr));
+      CK(pio_lm_prefill(v, prompt.data(), 4, 9, logp.data(), nullptr));
+      CK(pio_beam_select(v, logp.data(), nullptr, nullptr, nullptr, 4, val.data(), idx.data(), nullptr));
+      CK(pio_lm_advance(v, nt.data(), nullptr, 4, 9, logp.data(), nullptr));
+      CK(pio_lm_advance(v, nt.data(), src.data(), 4, 10, logp.data(), nullptr));
+      CK(pio_beam_select(v, logp.data(), sc.data(), ln.data(), st.data(), 4, val.data(), idx.data(), nullptr));
+      EXPECT_FAIL(pio_beam_select(v, logp.data(), sc.data(), nullptr, st.data(), 4, val.data(), idx.data(), nullptr));
+      EXPECT_FAIL(pio_beam_select(v, logp.data(), nullptr, nullptr, nullptr, 9, val.data(), idx.data(), nullptr));
+      EXPECT_FAIL(pio_lm_prefill(v, prompt.data(), 5, 9, logp.data(), nullptr));        // above max_prefixes
+      EXPECT_FAIL(pio_lm_advance(v, nt.data(), nullptr, 4, 4096, logp.data(), nullptr));
+    }
     EXPECT_FAIL(pio_decode_greedy(v, prefix.data(), 2, 30, ids.data(), nullptr, nullptr));             // no clip_project in a ViECap model
     CK(pio_destroy(v));
   }
