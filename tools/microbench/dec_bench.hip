@@ -128,7 +128,7 @@ int main(int argc, char** argv) {
   printf("fc2  (resid)       %7.2f us\n", time_chain([&] { dec_gemm<DE_RESID, 0>(w_fc2, hid, N, E, 4 * E, bias, x, nullptr, nullptr, 0.f, ws, cnt, s); }));
   printf("lm head (argmax)   %7.2f us\n", time_chain([&] { launch_lmhead(w_head, x, N, V, E, bias, cvec, 1e-5f, part, &nblk, s); }, 50));
   printf("lm head generic    %7.2f us\n", time_chain([&] { dec_gemm<DE_ARGMAX, 1>(w_head, x, N, V, E, bias, part, nullptr, cvec, 1e-5f, nullptr, nullptr, s); }, 50));
-  printf("select             %7.2f us\n", time_chain([&] { hipLaunchKernelGGL(k_dec_select, dim3(N), dim3(256), 0, s, part, nblk, N, E, 3, S, wte, wpe, ids, lp, x); }));
+  printf("select             %7.2f us\n", time_chain([&] { hipLaunchKernelGGL(k_dec_select, dim3(N), dim3(256), 0, s, part, nblk, N, E, 3, S, wte, wpe, ids, lp, x, 0); }));
   CK(hipDeviceSynchronize());
   return 0;
 }
