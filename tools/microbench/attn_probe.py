@@ -1,5 +1,5 @@
 """k_vit_attention per-launch time inside a ViT forward (HIP-event brackets of the PIO_PROF_VIT_ATTN class), and a checksum of
-the tokens so that two builds / variants can be compared:  [PIO_ATTN_V2=1] python tools/microbench/attn_probe.py [B ...]"""
+the tokens so that two builds / variants can be compared:  [PIO_LIB_PATH=<variant .so>] python tools/microbench/attn_probe.py [B ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,5 +1,5 @@
 """Ten 32-query projection passes over the full-size bank and nothing else (the program rocprofv3 --pmc collects counters on):
-    [PIO_PROJECT_V1=1 | PIO_PROJECT_SHIFT=1] rocprofv3 --pmc ... -- python3 tools/microbench/project_run.py [N]"""
+    [PIO_PROJECT_EXACT=1] rocprofv3 --pmc ... -- python3 tools/microbench/project_run.py [N]      (tools/microbench/pmc_project.sh)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
