@@ -218,7 +218,7 @@ def main():
     VB = max(1, min(args.vit_batches, P)) if args.mode == "group" else 1
     DS = max(1, args.decode_streams)
     models = build_models(local, P if args.mode == "streams" else S,
-                          max_prefixes=min(128, max(64, BATCH * P)) if args.mode == "group" else 64, max_batch=BATCH * VB)
+                          max_prefixes=min(256, max(64, BATCH * P)) if args.mode == "group" else 64, max_batch=BATCH * VB)
     model = models[0]
     streams = [torch.cuda.Stream() for _ in range(P)]
     imgs, traces = make_inputs()

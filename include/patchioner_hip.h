@@ -66,7 +66,7 @@ typedef struct {
   float   dec_ln_eps;         /* 1e-5 */
   /* capacities */
   int32_t max_batch;          /* images per pio_vit_forward call */
-  int32_t max_prefixes;       /* prefixes per pio_decode_greedy / pio_mem_project call */
+  int32_t max_prefixes;       /* prefixes per pio_decode_greedy / pio_mem_project call, <= 256 (log-probabilities: 64 rows per call) */
   int32_t max_steps;          /* decode steps (reference: 30) */
   /* numerics of the ViT MFMA path: 0 = fp16 operands, 1 = bf16 operands (fp32 accumulate either way); 2 = exact fp32
    * operands on the fp32 MFMA, a PARITY mode (plain kernels, ~20x slower) in which the whole path is held to the fp32

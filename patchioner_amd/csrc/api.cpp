@@ -470,8 +470,8 @@ int alloc_decoder_workspaces(pio_context* c) {
   if ((rc = c->dmalloc(&c->dqkv, N * 3 * E, true))) return rc;
   if ((rc = c->dmalloc(&c->datt, N * E, true))) return rc;
   if ((rc = c->dmalloc(&c->dhid, N * 4 * E, true))) return rc;
-  if ((rc = c->dmalloc(&c->splitk_ws, (size_t)64 * 4 * 8 * 256, true))) return rc;   // 64 column groups x 4 k-slices x 8 row groups
-  if ((rc = c->dmalloc(&c->splitk_cnt, 64, true))) return rc;
+  if ((rc = c->dmalloc(&c->splitk_ws, (size_t)DEC_SPLITK_COUNTERS * 4 * 8 * 256, true))) return rc;   // tiles x 4 k-slices x 8 (column, row) group pairs
+  if ((rc = c->dmalloc(&c->splitk_cnt, DEC_SPLITK_COUNTERS, true))) return rc;
   if ((rc = c->dmalloc(&c->kcache, (size_t)L * N * S * E, true))) return rc;
   if ((rc = c->dmalloc(&c->vcache, (size_t)L * N * S * E, true))) return rc;
   if ((rc = c->dmalloc(&c->logits, N * (size_t)round_up(V, 64), true))) return rc;
@@ -647,8 +647,8 @@ int pio_create(const pio_config* cfg, pio_handle* out) {
     return fail(PIO_ERR_INVALID_ARG, "pio_create: backbone head_dim must be 64 (embed_dim = 64 * num_heads)");
   if (cfg->crop_dim % cfg->patch_size != 0)
     return fail(PIO_ERR_INVALID_ARG, "pio_create: crop_dim must be a multiple of patch_size");
-  if (cfg->max_batch < 1 || cfg->max_prefixes < 1 || cfg->max_prefixes > 128 || cfg->max_steps < 1 || cfg->max_steps > 256)
-    return fail(PIO_ERR_INVALID_ARG, "pio_create: capacities out of range (prefixes <= 128, decoder positions <= 256)");
+  if (cfg->max_batch < 1 || cfg->max_prefixes < 1 || cfg->max_prefixes > DEC_MAX_PREFIXES || cfg->max_steps < 1 || cfg->max_steps > 256)
+    return fail(PIO_ERR_INVALID_ARG, "pio_create: capacities out of range (prefixes <= 256, decoder positions <= 256)");
   if (cfg->readout_heads != 16 && cfg->readout_heads * 64 != cfg->embed_dim)
     return fail(PIO_ERR_INVALID_ARG, "pio_create: readout_heads must be 16, or embed_dim / 64 (ViT-S: 6)");
   if (cfg->vit_arch != 0 && cfg->vit_arch != 1) return fail(PIO_ERR_INVALID_ARG, "pio_create: vit_arch must be 0 (DINOv2) or 1 (OpenAI-CLIP ViT)");
@@ -1165,7 +1165,7 @@ int pio_decode_greedy(pio_handle c, const float* prefix, int32_t N, int32_t step
   a.head_w16 = c->head_w16; a.head_w16_unscale = c->head_w16_unscale; a.head_bound_coef = c->head_bound_coef;
   a.xh = c->dec_xh; a.lm_stats = c->lm_stats; a.lm_gmax = c->lm_gmax;
   HIP_OK(hipMemcpyAsync(c->prefix_buf, prefix, (size_t)N * PS * 4, hipMemcpyDeviceToDevice, s));
-  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, 64 * sizeof(unsigned), s));   // tickets start at zero whatever happened before
+  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, DEC_SPLITK_COUNTERS * sizeof(unsigned), s));   // tickets start at zero whatever happened before
   // algorithmic work of a KV-cached decode: per token 4 layers x 12 E^2 MACs + the tied LM head;
   // bytes = every fp32 weight read once per step
   const double layer_params = (double)c->cfg.dec_layers * 12.0 * E * E, head_params = (double)c->cfg.dec_vocab * E;
@@ -1259,7 +1259,7 @@ int pio_lm_score(pio_handle c, const int32_t* tokens, const int32_t* lens, int32
   a.kcache = c->kcache; a.vcache = c->vcache; a.max_steps = c->cfg.max_steps; a.logits = c->logits; a.ids = c->ids_buf; a.logprob = nullptr;
   a.head_w16 = c->head_w16; a.head_w16_unscale = c->head_w16_unscale; a.head_bound_coef = c->head_bound_coef;
   a.xh = c->dec_xh; a.lm_stats = c->lm_stats; a.lm_gmax = c->lm_gmax; a.pos_base = 0;
-  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, 64 * sizeof(unsigned), s));
+  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, DEC_SPLITK_COUNTERS * sizeof(unsigned), s));
   HIP_OK(launch_lm_score(a, tokens, lens, Lmax, nll, s));
   return PIO_OK;
 }
@@ -1308,7 +1308,7 @@ int pio_lm_prefill(pio_handle c, const float* embeds, int32_t N, int32_t P, floa
   if ((rc = beam_scratch(c))) return rc;
   hipStream_t s = (hipStream_t)stream;
   const DecoderArgs a = lm_args(c, N);
-  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, 64 * sizeof(unsigned), s));
+  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, DEC_SPLITK_COUNTERS * sizeof(unsigned), s));
   HIP_OK(launch_lm_prefill(a, embeds, P, c->beam_stats, logp, s));
   return PIO_OK;
 }
@@ -1323,7 +1323,7 @@ int pio_lm_advance(pio_handle c, const int32_t* tokens, const int32_t* src_rows,
   if ((rc = beam_scratch(c))) return rc;
   hipStream_t s = (hipStream_t)stream;
   const DecoderArgs a = lm_args(c, N);
-  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, 64 * sizeof(unsigned), s));
+  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, DEC_SPLITK_COUNTERS * sizeof(unsigned), s));
   HIP_OK(launch_lm_advance(a, tokens, src_rows, pos, c->beam_k, c->beam_v, c->beam_stats, logp, s));
   return PIO_OK;
 }
@@ -1366,7 +1366,7 @@ int pio_viecap_decode(pio_handle c, const float* cont, const int32_t* tokens, in
   a.kcache = c->kcache; a.vcache = c->vcache; a.max_steps = c->cfg.max_steps; a.logits = c->logits; a.ids = c->ids_buf; a.logprob = nullptr;
   a.head_w16 = c->head_w16; a.head_w16_unscale = c->head_w16_unscale; a.head_bound_coef = c->head_bound_coef;
   a.xh = c->dec_xh; a.lm_stats = c->lm_stats; a.lm_gmax = c->lm_gmax; a.pos_base = P - 1;
-  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, 64 * sizeof(unsigned), s));
+  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, DEC_SPLITK_COUNTERS * sizeof(unsigned), s));
   if (c->use_graph) {
     const pio_context::PKey key{N, P, steps};
     auto it = c->pgraphs.find(key);

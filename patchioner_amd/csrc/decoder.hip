@@ -78,8 +78,9 @@ namespace pio {
 #define PIO_LMHEAD_CG 1
 #endif
 
-static constexpr int DEC_MAX_COLGROUPS = 64;   // split-K counters / slabs are sized for Nout <= 1024
-static constexpr size_t DEC_SPLITK_WS_FLOATS = (size_t)64 * 4 * 8 * 256;   // api.cpp: splitk_ws
+static constexpr int DEC_MAX_COLGROUPS = 128;  // split-K counters / slabs: Nout <= 1024 at <= 128 prefixes, fc2's 24 x 4 tiles at 256 (kernels.h: DEC_SPLITK_*)
+static constexpr size_t DEC_SPLITK_WS_FLOATS = (size_t)DEC_SPLITK_COUNTERS * 4 * 8 * 256;   // api.cpp: splitk_ws
+static_assert(DEC_MAX_COLGROUPS == DEC_SPLITK_COUNTERS, "kernels.h");
 
 enum DecEpi { DE_STORE = 0, DE_RESID = 1, DE_GELU = 2, DE_EMBED = 3, DE_ARGMAX = 4 };
 
@@ -727,7 +728,7 @@ template <int RGB, int NCG, int KS, int EPI, int LN>
 static hipError_t dec_gemm_b_launch(const float* W, const float* X, int N, int Nout, int K, const float* bias, float* out,
                                     const float* cvec, float eps, float* ws, unsigned* cnt, hipStream_t s) {
   const dim3 grid(Nout / (16 * NCG), KS, ceil_div(N, 16 * RGB));
-  if (K != KS * 768 || Nout % (16 * NCG) != 0 || N < 1 || N > 128) return hipErrorInvalidValue;
+  if (K != KS * 768 || Nout % (16 * NCG) != 0 || N < 1 || N > DEC_MAX_PREFIXES) return hipErrorInvalidValue;
   if (KS > 1 && ((int)(grid.x * grid.z) > DEC_MAX_COLGROUPS || (size_t)grid.x * grid.z * KS * NCG * RGB * 256 > DEC_SPLITK_WS_FLOATS || !ws || !cnt))
     return hipErrorInvalidValue;
   constexpr int RB = RGB == 4 ? 8 : 12;
@@ -747,7 +748,15 @@ static hipError_t dec_gemm_b_launch(const float* W, const float* X, int N, int N
 template <int EPI, int LN>
 static hipError_t dec_gemm(const float* W, const float* X, int N, int Nout, int K, const float* bias, float* out,
                            const float* extra, const float* cvec, float eps, float* ws, unsigned* cnt, hipStream_t s) {
-  if (N < 1 || N > 128) return hipErrorInvalidValue;
+  if (N < 1 || N > DEC_MAX_PREFIXES) return hipErrorInvalidValue;
+  if constexpr (EPI == DE_EMBED) {
+    // the prefix projection runs once per decode on k_dec_gemm (<= 128 rows per launch): 129 .. 256 prefixes as two launches
+    if (N > 128) {
+      hipError_t e = dec_gemm<EPI, LN>(W, X, 128, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);
+      if (e != hipSuccess) return e;
+      return dec_gemm<EPI, LN>(W, X + (size_t)128 * K, N - 128, Nout, K, bias, out + (size_t)128 * Nout, extra, cvec, eps, ws, cnt, s);
+    }
+  }
   if constexpr (PIO_DEC_TILED != 0 && (EPI == DE_STORE || EPI == DE_RESID || EPI == DE_GELU)) {
     const int rg = ceil_div(N, 16);
     if (rg >= 2 && K == 768 && Nout % 48 == 0) {
@@ -760,7 +769,7 @@ static hipError_t dec_gemm(const float* W, const float* X, int N, int Nout, int 
                   : dec_gemm_b_launch<1, 1, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
     }
     if constexpr (EPI == DE_RESID && !LN) {
-      if (rg >= 2 && K == 3072 && Nout % 32 == 0 && Nout <= 32 * (DEC_MAX_COLGROUPS / 2) && ws != nullptr && cnt != nullptr) {
+      if (rg >= 2 && K == 3072 && Nout % 32 == 0 && Nout <= 1024 && ws != nullptr && cnt != nullptr) {
         if (rg > 4) return dec_gemm_b_launch<4, 2, 4, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
         if (rg > 2) return dec_gemm_b_launch<2, 2, 4, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
         return dec_gemm_b_launch<1, 2, 4, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
@@ -770,7 +779,7 @@ static hipError_t dec_gemm(const float* W, const float* X, int N, int Nout, int 
   if (K == 768) return dec_gemm_rg<12, 1, EPI, LN>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);
   if (K == 512) return dec_gemm_rg<8, 1, EPI, LN>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);
   if (K == 384) return dec_gemm_rg<6, 1, EPI, LN>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);   // ViT-S prefix
-  if (K == 3072 && EPI == DE_RESID && !LN && ws != nullptr && cnt != nullptr && Nout <= 16 * DEC_MAX_COLGROUPS)
+  if (K == 3072 && EPI == DE_RESID && !LN && ws != nullptr && cnt != nullptr && Nout <= 1024)
     return dec_gemm_rg<12, 4, DE_RESID, 0>(W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt, s);
   return hipErrorInvalidValue;
 }
@@ -1367,7 +1376,8 @@ static hipError_t launch_lmhead_filtered(const DecoderArgs& a, int step, hipStre
   else if (rg <= 1) e = launch_lmhead_f16<1>(a, s);
   else if (rg <= 2) e = launch_lmhead_f16<2>(a, s);
   else if (rg <= 4) e = launch_lmhead_f16<4>(a, s);
-  else e = launch_lmhead_f16<8>(a, s);
+  else if (rg <= 8) e = launch_lmhead_f16<8>(a, s);
+  else e = launch_lmhead_f16<16>(a, s);             // 129 .. 256 prefixes: 32-KB X~ chunks, the weights still read once
   if (e != hipSuccess) return e;
   const int NG = ceil_div(a.vocab, 16), NGp = round_up(NG, 64);
   if (NG > 4096) return hipErrorInvalidValue;
@@ -1420,7 +1430,7 @@ static hipError_t dec_head_step(const DecoderArgs& a, int step, bool filtered, h
 
 static bool dec_args_ok(const DecoderArgs& a, bool filtered, int positions) {
   return positions <= a.max_steps && positions <= 256 && a.steps <= 64 && a.E == 768 && (a.E / a.heads) % 32 == 0 &&
-         (a.E / a.heads) <= 256 && a.N <= (filtered ? 128 : 64) && ceil_div(a.vocab, 16) <= 4096;
+         (a.E / a.heads) <= 256 && a.N <= (filtered ? DEC_MAX_PREFIXES : 64) && ceil_div(a.vocab, 16) <= 4096;
 }
 
 hipError_t launch_decode_greedy(const DecoderArgs& a, hipStream_t s) {

@@ -135,6 +135,8 @@ struct DecLayerW {
   const float *attn_w /*[3E][E] folded*/, *attn_c, *attn_d, *proj_w /*[E][E]*/, *proj_b;
   const float *fc_w /*[4E][E] folded*/, *fc_c, *fc_d, *fc2_w /*[E][4E]*/, *fc2_b;
 };
+static constexpr int DEC_MAX_PREFIXES = 256;       // rows of one greedy decode (ids only; log-probabilities: 64 per call)
+static constexpr int DEC_SPLITK_COUNTERS = 128;    // arrival tickets / slab groups of the in-launch split-K (api.cpp allocates them)
 struct DecoderArgs {
   int N, steps, E, heads, layers, vocab, prefix_size;
   float eps;

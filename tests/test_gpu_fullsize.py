@@ -24,7 +24,7 @@ def full():
         bank[s:s + 65536] = torch.randn(min(65536, M_FULL - s), 768, device="cuda", generator=g)
     cfg = {"decap_weights": W.synth_decap(3), "dino_weights": W.synth_dinov2(1), "memory_bank": bank, "prefix_size": 768,
            "linear_talk2dino": False, "support_memory_size": M_FULL, "dino_model": "dinov2_vitb14_reg", "normalize": True,
-           "resize_dim": 224, "crop_dim": 224, "max_batch": 16, "max_prefixes": 128}
+           "resize_dim": 224, "crop_dim": 224, "max_batch": 16, "max_prefixes": 256}
     m = Patchioner.from_config(cfg, device="cuda")
     imgs = W.synth_images(9, 16, 224).cuda()
     traces = [gc.block_trace(int(i * 5 % 13), int(i * 7 % 13)) for i in range(16)]
@@ -70,9 +70,13 @@ def test_decoder_rows_are_independent_at_every_batch_size(full):
     x = torch.randn(16, 768, device="cuda", generator=g)
     x = x / x.norm(dim=-1, keepdim=True)
     ids16, _ = m.engine.decode_greedy(x)
-    for reps in (2, 4, 8):                                               # 32, 64, 128 prefixes: other kernels, same rows
+    for reps in (2, 4, 8, 11, 16):                                       # 32 .. 256 prefixes: other kernels / tile shapes, same rows
         ids, _ = m.engine.decode_greedy(x.repeat(reps, 1))
         assert torch.equal(ids.view(reps, 16, -1), ids16.expand(reps, -1, -1)), reps
+    y = torch.randn(200, 768, device="cuda", generator=g)                # a ragged count above 128: one decode = two decodes
+    y = y / y.norm(dim=-1, keepdim=True)
+    whole, _ = m.engine.decode_greedy(y)
+    assert torch.equal(whole, torch.cat([m.engine.decode_greedy(y[:128])[0], m.engine.decode_greedy(y[128:])[0]]))
     ids_lp, lp = m.engine.decode_greedy(x, want_logprob=True)            # exact head vs filtered head
     assert torch.equal(ids_lp, ids16) and torch.isfinite(lp).all() and (lp <= 0).all()
 
