@@ -116,14 +116,57 @@ class TraceCaptionPipeline:
         # and default priorities; decode streams high and stage normal: 8.52 k; both high: 8.57 k).
         self.stage_streams = [self._make_stream(stage_cus, priority=int(os.environ.get("PIO_STAGE_PRIO", "-1"))) for _ in self.stage_models]
         # ... and the decode to the LAST `decode_cus` compute units (a true partition when stage_cus + decode_cus <= total)
-        self.decode_streams = [self._make_stream(decode_cus, from_top=True, priority=int(os.environ.get("PIO_DECODE_PRIO", "0")))
-                               for _ in self.decode_engines]
+        if decode_cus:
+            self.decode_streams = [self._make_stream(decode_cus, from_top=True) for _ in self.decode_engines]
+        else:
+            self.decode_streams = self._concurrent_streams(len(self.decode_engines), int(os.environ.get("PIO_DECODE_PRIO", "0")),
+                                                           beside=self.stage_streams)
         self.sb = self.decode_streams[0]
         self._ndecoded = 0
         self._nstaged = 0
         cap = self.eng.max_prefixes
         self.groups = [_Group(cap, self.eng.prefix_size, steps, self.eng.device) for _ in range(1 + len(self.decode_engines))]
         self.last_ids: Optional[torch.Tensor] = None
+
+    def _concurrent_streams(self, n: int, priority: int = 0, candidates: int = 16, beside: Sequence = ()) -> List[torch.cuda.Stream]:
+        """``n`` streams that the device really runs side by side.  HIP deals the streams of a priority class round-robin onto
+        its few hardware queues (GPU_MAX_HW_QUEUES, default 4) in creation order -- the caller's, torch's and this library's own
+        included -- and two streams that share a queue run one after the other: whether three decode streams overlap depended
+        on what had been created before them (BASELINE config 3 through RegionCaptionPipeline: 6.8 or 10.3 k box captions/s for
+        the same settings).  So candidates are taken from torch's pool and PROBED: a spin kernel on each stream of the set at
+        once takes the time of one when they run concurrently, the sum when two share a queue (about 1 ms in all, once).
+        ``beside``: streams the chosen ones must also be concurrent with (stage 1's)."""
+        beside = list(beside)
+        if n < 1 or (n == 1 and not beside) or os.environ.get("PIO_PROBE_STREAMS", "1") == "0" or not hasattr(torch.cuda, "_sleep"):
+            return [torch.cuda.Stream(priority=priority) for _ in range(n)]
+        import time
+        dev = self.eng.device
+        spin = 400_000                                        # cycles: ~0.2 ms
+
+        def wall(streams):
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            for st in streams:
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(spin)
+            torch.cuda.synchronize(dev)
+            return time.perf_counter() - t
+
+        probe = torch.cuda.Stream(priority=priority)
+        wall([probe])                                         # warm
+        base = min(wall([probe]) for _ in range(3))
+        chosen, spare = [], []
+        for cand in [probe] + [None] * candidates:
+            if len(chosen) == n:
+                break
+            cand = cand if cand is not None else torch.cuda.Stream(priority=priority)
+            if any(cand.cuda_stream == c.cuda_stream for c in chosen + spare):
+                continue                                      # the pool has wrapped around
+            if min(wall(beside + chosen + [cand]) for _ in range(2)) < 1.45 * base:
+                chosen.append(cand)
+            else:
+                spare.append(cand)
+        return chosen + spare[:n - len(chosen)]               # not enough independent queues: take what there is
 
     def _make_stream(self, n_cus, from_top: bool = False, priority: int = 0):
         if not n_cus:

@@ -9,7 +9,7 @@ B, NB, crop = 8, 16, 518
 bank = W.synth_bank(2, 591753)
 cfg = {"decap_weights": W.synth_decap(3), "prefix_size": 768, "linear_talk2dino": False, "support_memory_size": 591753,
        "dino_model": "dinov2_vitb14_reg", "normalize": True, "resize_dim": crop, "crop_dim": crop,
-       "dino_weights": W.synth_dinov2(1, "dinov2_vitb14_reg"), "memory_bank": bank, "max_batch": B, "max_prefixes": 128}
+       "dino_weights": W.synth_dinov2(1, "dinov2_vitb14_reg"), "memory_bank": bank, "max_batch": B, "max_prefixes": 256}
 m = Patchioner.from_config(cfg, device="cuda")
 imgs = W.synth_images(5, B, crop).cuda()
 rng = np.random.RandomState(4)
@@ -31,13 +31,13 @@ for k, v in m.engine.profile_read().items():
 
 # the same shape through the pipeline (RegionCaptionPipeline + BoxRegions): stage 1 of batch i+1 under the decode of batch i
 from patchioner_amd.pipeline import RegionCaptionPipeline, BoxRegions
-for clones in (1, 2):
-    pipe = RegionCaptionPipeline(m, group_batches=1, decode_clones=clones)
+for clones, gb in ((1, 1), (2, 1), (1, 2), (2, 2)):          # gb = 2: one greedy decode per 256 boxes
+    pipe = RegionCaptionPipeline(m, group_batches=gb, decode_clones=clones)
     list(pipe.run((imgs, BoxRegions(boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=1.0)) for _ in range(4)))
     torch.cuda.synchronize(); t = time.perf_counter()
     n = 24
     for _ in pipe.run((imgs, BoxRegions(boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=1.0)) for _ in range(n)):
         pass
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
-    print("config 3 shape, pipelined (%d decodes in flight): %.2f ms per batch = %.0f box captions/s" % (1 + clones, dt * 1e3, B * NB / dt))
+    print("config 3 shape, pipelined (%d decodes in flight, %d boxes per decode): %.2f ms per batch = %.0f box captions/s" % (1 + clones, gb * B * NB, dt * 1e3, B * NB / dt))
     pipe.close()
