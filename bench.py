@@ -421,6 +421,10 @@ def main():
             "config": {"workload": "talk2dino_decap_COCO, ViT-B/14-reg 224^2, batch 16/GPU, caption_from=patches "
                                    "(one 16-patch trace region per image), bank 591753x768 fp32, 30-step greedy decode; `value` is measured "
                                    "through the throughput API (value_api), the drop-in forward() figure is forward_sync",
+                       "arithmetic": {"vit": "fp16 operands, fp32 accumulation (v_mfma_f32_32x32x16_f16), fp32 residual stream / LayerNorm",
+                                      "projection": "operands as fp16 hi + lo pairs (22 significant bits) on v_mfma_f32_16x16x32_f16, fp32 "
+                                                    "accumulation and soft-max; as close to fp64 as an fp32 evaluation (DESIGN.md section 3)",
+                                      "decoder": "fp32 (v_mfma_f32_16x16x4_f32); greedy ids through an fp16 filter + exact fp32 re-evaluation"},
                        "global_batch": BATCH * world, "parallelism": "dp%d (image shards, ids all-gather)" % world, "batches_in_flight_per_gpu": P, "batches_per_vit_launch": VB, "concurrent_decodes": DS if args.mode == "group" else 1,
                        "pipelining": "none" if P == 1 else ("one decode per %d batches (up to %d decodes in flight, one decoder clone and stream each), overlapped with the next batches' ViT (one launch per %d batches) on %d stream(s)" % (P, DS, VB, S)
                                                            if args.mode == "group" else "%d forwards on %d streams" % (P, P))},
