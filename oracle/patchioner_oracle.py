@@ -140,13 +140,25 @@ class ClipViTOracle:
         self.D = self.w["head.weight"].shape[0]      # width of the tokens handed on (512 for ViT-B)
         self.last_qkv = None
 
+    def pos_embed_for(self, n_h: int, n_w: int) -> torch.Tensor:
+        """timm.layers.resample_abs_pos_embed (public; called from vision_transformer.checkpoint_filter_fn when
+        ``timm.create_model(..., img_size=resize_dim)``, P/src/model.py:371, meets a checkpoint of another grid): the prefix
+        (class) position is kept apart, the grid goes through F.interpolate(size=, mode='bicubic', antialias=True)."""
+        pe = self.w["pos_embed"].reshape(1, -1, self.Dv)
+        g = int(math.isqrt(pe.shape[1] - 1))
+        if (n_h, n_w) == (g, g):
+            return pe
+        grid = pe[:, 1:].reshape(1, g, g, self.Dv).permute(0, 3, 1, 2)
+        grid = F.interpolate(grid, size=(n_h, n_w), mode="bicubic", antialias=True)
+        return torch.cat([pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, n_h * n_w, self.Dv)], dim=1)
+
     def forward_features(self, imgs: torch.Tensor) -> torch.Tensor:
         w, D, h = self.w, self.Dv, self.num_heads
         B = imgs.shape[0]
         x = F.conv2d(imgs.float(), w["patch_embed.proj.weight"], w.get("patch_embed.proj.bias"), stride=self.patch_size)
         x = x.flatten(2).transpose(1, 2)
         x = torch.cat([w["cls_token"].reshape(1, 1, D).expand(B, -1, -1), x], dim=1)
-        x = x + w["pos_embed"].reshape(1, -1, D)                 # native grid: timm resamples for other sizes (not restated)
+        x = x + self.pos_embed_for(imgs.shape[-2] // self.patch_size, imgs.shape[-1] // self.patch_size)
         x = F.layer_norm(x, (D,), w["norm_pre.weight"], w["norm_pre.bias"], self.eps)
         T = x.shape[1]
         for i in range(self.depth):

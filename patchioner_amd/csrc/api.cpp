@@ -254,8 +254,10 @@ int finalize_vit(pio_context* c) {
     std::vector<float> pos((size_t)(1 + c->n2) * D);
     // hub variants: *_reg models interpolate with antialias and offset 0, the models without registers without
     // antialias and with the historical 0.1 offset (dinov2/hub/backbones.py)
-    if (clip) pos.assign(t->data.begin(), t->data.end());            // native grid (pio_create): the learned table as it is
-    else if (R > 0) interpolate_pos_embed(t->data.data(), g, D, c->n, pos.data());
+    // CLIP (timm.create_model(..., img_size=resize_dim), P/src/model.py:371): the checkpoint's table is resampled at load by
+    // timm's resample_abs_pos_embed -- class position kept apart, F.interpolate(size=, mode="bicubic", antialias=True) on the
+    // grid -- the same arithmetic as the *_reg DINOv2 models; identity at the native 224 x 224 (configs/decap_B16_resize.k.yaml: 592)
+    if (clip || R > 0) interpolate_pos_embed(t->data.data(), g, D, c->n, pos.data());
     else interpolate_pos_embed_plain(t->data.data(), g, D, c->n, 0.1, pos.data());
     if ((rc = upload_f32(c, pos.data(), pos.size(), &c->pos))) return rc;
   }
@@ -652,8 +654,8 @@ int pio_create(const pio_config* cfg, pio_handle* out) {
   if (cfg->readout_heads != 16 && cfg->readout_heads * 64 != cfg->embed_dim)
     return fail(PIO_ERR_INVALID_ARG, "pio_create: readout_heads must be 16, or embed_dim / 64 (ViT-S: 6)");
   if (cfg->vit_arch != 0 && cfg->vit_arch != 1) return fail(PIO_ERR_INVALID_ARG, "pio_create: vit_arch must be 0 (DINOv2) or 1 (OpenAI-CLIP ViT)");
-  if (cfg->vit_arch == 1 && (cfg->num_registers != 0 || cfg->pretrain_grid * cfg->patch_size != cfg->crop_dim))
-    return fail(PIO_ERR_INVALID_ARG, "pio_create: the CLIP ViT has no registers and runs at its native grid (crop_dim = pretrain_grid * patch_size)");
+  if (cfg->vit_arch == 1 && cfg->num_registers != 0)
+    return fail(PIO_ERR_INVALID_ARG, "pio_create: the CLIP ViT has no registers");
   if (cfg->vit_out_dim < 0 || (cfg->vit_out_dim > 0 && cfg->vit_out_dim % 32 != 0) || (cfg->vit_arch == 0 && cfg->vit_out_dim != 0 && cfg->vit_out_dim != cfg->embed_dim))
     return fail(PIO_ERR_INVALID_ARG, "pio_create: vit_out_dim must be 0, or a multiple of 32 with vit_arch 1");
   int ndev = 0;

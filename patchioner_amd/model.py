@@ -102,9 +102,10 @@ class Patchioner(nn.Module):
         if dino_model is None or 'dinotxt' in dino_model or not ('dinov2' in dino_model or is_clip):
             raise ValueError("Unsupported backbone %r: this build implements the DINOv2 ViT-S/B/L-14 family and the timm "
                              "OpenAI-CLIP ViTs (vit_base_patch16/32_clip_224.openai)" % (dino_model,))
-        if is_clip and (resize_dim != 224 or crop_dim != 224):
-            # the reference hands img_size=resize_dim to timm, which resamples the position table for any other size
-            raise NotImplementedError("the CLIP ViT runs at its native 224 x 224 (timm would resample its position table)")
+        if is_clip and resize_dim != crop_dim:
+            # P/src/model.py:371 builds the tower with img_size=resize_dim: timm's PatchEmbed then asserts that every input is
+            # resize_dim x resize_dim, while the transforms crop to crop_dim -- the reference's first forward fails; fail at once
+            raise AssertionError("Input height (%d) doesn't match model (%d)." % (crop_dim, resize_dim))
         if viecap_config is not None and viecap_config.get('meacap', False):
             raise NotImplementedError("MeaCap head (retrieved-caption scene graphs, flan-T5): outside the hot-path scope")
         if decoder_weights is None and synthetic_seed is None and not calculate_argmax_text and viecap_config is None:
@@ -136,7 +137,8 @@ class Patchioner(nn.Module):
         self.num_global_tokens = 1 if "reg" not in dino_model else 5
         if is_clip:
             # timm VisionTransformer with pre_norm, nn.LayerNorm (eps 1e-5), QuickGELU (model.py:363-371); the reference hands
-            # img_size=resize_dim to timm, which resamples the position table for any other size: native size only here
+            # img_size=resize_dim to timm, which resamples the checkpoint's position table for any size but 224 at load
+            # (configs/decap_B16_resize.k.yaml: 592): pio_finalize_weights does the same from the table's own grid
             self.embed_dim, depth, heads, patch_size, self.token_dim = W.clip_arch(dino_model)
         else:
             patch_size = 14

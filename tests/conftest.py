@@ -62,3 +62,30 @@ def _oracle_decoder_keeps_keys_and_values(request):
     O.DeCapOracle.fast = True
     yield
     O.DeCapOracle.fast = old
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The parity ledger survives ``pytest -q``: one line per caption set that went through the fp16 / bf16 backbone --
+    identical / total, departures, the largest reference margin at a departure, the largest prefix error -- and the same
+    records in tests/_parity_report.json (and gpurun_out/, when the run is on a GPU box)."""
+    try:
+        import parity_helpers as ph
+    except ImportError:
+        return
+    if not ph.REPORT:
+        return
+    tr = terminalreporter
+    tr.write_line("")
+    tr.write_line("parity report (%d caption sets; captions identical to the fp32 reference / total):" % len(ph.REPORT))
+    tot = dep = 0
+    for r in ph.REPORT:
+        tot, dep = tot + r["total"], dep + r["departures"]
+        tr.write_line("  %4d / %4d  dep %d  margin %.1e  shift %.1e  prefix-err %s  [%s] %s" % (
+            r["identical"], r["total"], r["departures"], r["worst_margin_at_departure"], r["max_logit_shift_at_departure"],
+            "%.1e" % r["max_prefix_rel_err"] if r["max_prefix_rel_err"] is not None else "n/a", r["bound"], r["label"]))
+    tr.write_line("  total: %d / %d identical, %d departures (each one a near-tie of the reference, asserted)" % (tot - dep, tot, dep))
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        import json
+        with open(os.path.join(out, "parity_report.json"), "w") as f:
+            json.dump(ph.REPORT, f, indent=1)

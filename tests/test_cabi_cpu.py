@@ -30,9 +30,20 @@ def test_every_declared_symbol_is_exported(lib):
     assert b"gfx950" in lib.pio_version()
 
 
-@pytest.mark.parametrize("n,D", [(16, 768), (8, 384), (37, 64), (20, 64)])
-def test_pos_embed_interpolation_matches_torch(lib, n, D):
-    g = 37
+def test_clip_position_table_resample_14_to_37_matches_the_fixture(lib):
+    """configs/decap_B16_resize.k.yaml (592 x 592 through a patch-16 CLIP ViT): the host resampling of the 14 x 14 table against the
+    table the 592 fixture's HF model carried (tools/oracle/gen_golden.py: gen_clip_hf_592 = the torch call timm makes)."""
+    from patchioner_amd import weights as W
+    g = np.load(os.path.join(ROOT, "tests", "golden", "clip_vit_hf_592.npz"))
+    pos = W.synth_clip_vit(87, "vit_base_patch16_clip_224.openai", depth=1)["pos_embed"][0].contiguous()
+    out = torch.empty(1 + 37 * 37, 768)
+    assert lib.pio_host_interpolate_pos_embed(pos.data_ptr(), 14, 768, 37, out.data_ptr()) == 0
+    np.testing.assert_allclose(out[::17, ::3].numpy(), g["pos_sample"], rtol=1e-5, atol=2e-7)
+    assert torch.equal(out[0], pos[0])
+
+
+@pytest.mark.parametrize("n,D,g", [(16, 768, 37), (8, 384, 37), (37, 64, 37), (20, 64, 37), (37, 96, 14), (24, 64, 7)])
+def test_pos_embed_interpolation_matches_torch(lib, n, D, g):
     pos = torch.randn(1 + g * g, D, generator=torch.Generator().manual_seed(n))
     out = torch.empty(1 + n * n, D)
     rc = lib.pio_host_interpolate_pos_embed(pos.data_ptr(), g, D, n, out.data_ptr())
@@ -93,9 +104,9 @@ def test_out_of_scope_options_raise():
         Patchioner.from_config(dict(base, dino_model="RN50x4"), device="cuda")
     with pytest.raises(ValueError):
         Patchioner.from_config(dict(base, dino_model="dinov2_vitl14_reg_dinotxt"), device="cuda")
-    with pytest.raises(NotImplementedError):     # the CLIP ViT variant is served at its native 224 x 224 only
-        Patchioner.from_config(dict(base, dino_model="vit_base_patch16_clip_224.openai", prefix_size=512, resize_dim=336,
-                                    crop_dim=336), device="cuda")
+    with pytest.raises(AssertionError, match="doesn't match model"):   # timm's tower is built for resize_dim (P/src/model.py:371) and
+        Patchioner.from_config(dict(base, dino_model="vit_base_patch16_clip_224.openai", prefix_size=512, resize_dim=336,   # asserts on
+                                    crop_dim=224), device="cuda")                                                        # crop_dim inputs
     with pytest.raises(Exception, match="projection_type"):
         Patchioner.from_config({"prefix_size": 768, "support_memory_size": 10, "decap_weights": "x.pt",
                                 "dino_model": "dinov2_vitb14_reg", "projection_type": "nonsense"}, device="cuda")

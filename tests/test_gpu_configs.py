@@ -496,6 +496,52 @@ def test_clip_vit_backbone_decap_original_config(O):
                                            - torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(3, 1, 1)).div(torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(3, 1, 1)).mean())) < 1e-4
 
 
+def test_clip_vit_backbone_decap_resize_config_592(O):
+    """P/configs/decap_B16_resize.k.yaml: the CLIP ViT-B/16 at resize_dim = crop_dim = 592 (37 x 37 patches; P/src/model.py:371:
+    timm.create_model(..., img_size=592) resamples the position table at load) -- every key of that YAML, with the tensors the
+    paths would name; cls / gaussian boxes / traces against the oracle, whose ClipViTOracle restates timm's resampling and is held
+    to HF CLIP at 592 in the CPU suite."""
+    from patchioner_amd import Patchioner
+    from patchioner_amd.tokenizer import ClipDetokenizer
+    name = "vit_base_patch16_clip_224.openai"
+    vit_sd, dec_sd = W.synth_clip_vit(41, name, depth=2), W.synth_decap(43, prefix_size=512)
+    assert vit_sd["pos_embed"].shape == (1, 197, 768)              # the checkpoint's own 14 x 14 table
+    bank = W.synth_bank(45, 2048, 512) * 2.0
+    cfg = {"decap_weights": dec_sd, "prefix_size": 512, "support_memory_size": 500000, "dino_model": name, "normalize": False,
+           "resize_dim": 592, "crop_dim": 592, "clip_model_name": "ViT-B/16", "use_talk2dino_project": False,
+           "projection_type": "coco", "dino_weights": vit_sd, "memory_bank": bank.clone(), "max_batch": 2}
+    m = Patchioner.from_config(cfg, device="cuda")
+    assert (m.backbone_type, m.patch_size, m.num_tokens, m.num_patch_tokens, m.resize_dim, m.crop_dim) == ("CLIP", 16, 1370, 1369, 592, 592)
+    dec = O.DeCapOracle(dec_sd)
+    vit = O.ClipViTOracle(vit_sd, num_heads=12, patch_size=16)
+    orc = O.PatchionerOracle(vit, dec, bank / bank.norm(dim=-1, keepdim=True), ClipDetokenizer().decode, normalize=False, crop_dim=592)
+    imgs = W.synth_images(47, 2, 592)
+    tokens, _ = m.engine.vit_forward(imgs, want_qkv=False)
+    d = vit(imgs)
+    ref = torch.cat([d["x_norm_clstoken"][:, None], d["x_norm_patchtokens"]], 1)
+    err = float((tokens.cpu() - ref).abs().max() / ref.abs().max())
+    print("CLIP ViT-B/16 at 592, depth 2: tokens rel-max-err %.2e" % err)
+    assert tokens.shape == (2, 1370, 512) and err <= 4e-3
+    rng = np.random.RandomState(11)
+    xy = rng.randint(0, 30, size=(2, 5, 2)) * 16.0
+    wh = rng.randint(1, 7, size=(2, 5, 2)) * 16.0 + rng.randint(0, 16, size=(2, 5, 2))
+    boxes = torch.tensor(np.concatenate([xy, wh], -1), dtype=torch.float32)
+    traces = [[{"x": 0.05 + 0.03 * i, "y": 0.9 - 0.02 * i} for i in range(24)], [{"x": (3 + i % 4 + 0.5) / 37, "y": (20 + i // 4 + 0.5) / 37} for i in range(16)]]
+    kw = dict(get_cls_capt=True, traces=traces, gaussian_avg=True, gaussian_bbox_variance=1.0)
+    m.call_log, orc.call_log, orc.prefix_log = [], [], []
+    mine = boxes.clone()
+    got = m(imgs.cuda(), bboxes=mine, **kw)
+    want = orc.forward(imgs.clone(), bboxes=boxes.clone(), **kw)
+    assert torch.equal(mine, boxes // 16)
+    assert set(got) == set(want) == {"cls_capt", "bbox_capts", "trace_capts"}
+    _, total = assert_ids_explained(dec, m.call_log, orc.call_log, "CLIP ViT-B/16 at 592 (decap_B16_resize)", ref_prefixes=orc.prefix_log)
+    assert total == 2 + 10 + 2
+    # device-side transforms at this size: shorter side to 592 (bicubic), centre crop 592, CLIP statistics
+    from PIL import Image
+    raw = gc.prep_image(303, 700, 640)
+    assert torch.equal(m.preprocess_images([raw]).cpu()[0], m.image_transforms(Image.fromarray(raw)))
+
+
 def test_box_pipeline_matches_synchronous_forward():
     """pipeline.RegionCaptionPipeline with BoxRegions (dense / region captioning, BASELINE configs 3 and 4: ViT + box weights +
     weighted means + projection of batch i+1 under the greedy decode of batch i) returns exactly forward(bboxes=...)'s nested

@@ -115,3 +115,27 @@ def test_hip_clip_vit_depth12_vs_hf_clip(golden, tag, name, patch, stride, dtype
     err = float((cmp - ref).abs().max() / ref.abs().max())
     print("HF CLIP %s [%s]: rel-max-err %.2e" % (tag, dtype, err))
     assert err <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp16", 4e-3), ("bf16", 3e-2)])
+def test_hip_clip_vit_at_592_vs_hf_clip(golden, dtype, tol):
+    """configs/decap_B16_resize.k.yaml (resize_dim = crop_dim = 592; P/src/model.py:371 hands img_size=592 to timm, which resamples the
+    14 x 14 position table at load): the HIP path gets the 14 x 14 table, resamples it on the host (pio_finalize_weights) and runs
+    T = 1 + 37 x 37 tokens; held to an HF CLIP vision model built natively for 592 x 592 (tools/oracle/gen_golden.py: gen_clip_hf_592)."""
+    from patchioner_amd.engine import Engine
+    g = golden("clip_vit_hf_592")
+    e = Engine(embed_dim=768, depth=12, num_heads=12, num_registers=0, crop_dim=592, patch_size=16, pretrain_grid=14,
+               max_batch=1, vit_dtype=dtype, vit_arch="clip", vit_out_dim=512, vit_ln_eps=1e-5, prefix_size=512)
+    try:
+        e.load_state_dict(W.synth_clip_vit(87, "vit_base_patch16_clip_224.openai", depth=12))
+        e.finalize()
+        got, _ = e.vit_forward(W.synth_images(89, 1, 592), want_qkv=False)
+        got = got.cpu()
+    finally:
+        e.close()
+    assert got.shape == (1, 1 + 37 * 37, 512) and torch.isfinite(got).all()
+    ref = torch.cat([torch.from_numpy(g["b16_cls"])[:, None], torch.from_numpy(g["b16_patch_sample"])], 1)
+    cmp = torch.cat([got[:, :1], got[:, 1::9]], 1)
+    err = float((cmp - ref).abs().max() / ref.abs().max())
+    print("HF CLIP b16 at 592 [%s]: rel-max-err %.2e" % (dtype, err))
+    assert err <= tol

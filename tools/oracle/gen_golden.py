@@ -354,13 +354,13 @@ def gen_vit_hf_variants():
     save("vit_hf_variants", **arrs)
 
 
-def _hf_clip(w, depth, patch, heads=12):
+def _hf_clip(w, depth, patch, heads=12, image_size=224):
     """transformers.CLIPVisionModelWithProjection (an independent implementation of the OpenAI vision tower) carrying a
     timm-named state dict ``w`` (weights.synth_clip_vit)."""
     from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
     D, out = w["cls_token"].shape[-1], w["head.weight"].shape[0]
     cfg = CLIPVisionConfig(hidden_size=D, intermediate_size=4 * D, num_hidden_layers=depth, num_attention_heads=heads,
-                           image_size=224, patch_size=patch, projection_dim=out, hidden_act="quick_gelu",
+                           image_size=image_size, patch_size=patch, projection_dim=out, hidden_act="quick_gelu",
                            layer_norm_eps=1e-5, attn_implementation="eager")
     m = CLIPVisionModelWithProjection(cfg).eval()
     sd = {"vision_model.embeddings.class_embedding": w["cls_token"].reshape(-1),
@@ -400,6 +400,27 @@ def gen_clip_hf():
     save("clip_vit_hf", **arrs)
 
 
+def gen_clip_hf_592():
+    """configs/decap_B16_resize.k.yaml (resize_dim = crop_dim = 592): P/src/model.py:371 builds the tower with
+    ``timm.create_model(dino_model, pretrained=True, img_size=592)``, i.e. timm resamples the checkpoint's 14 x 14 position
+    table to 37 x 37 AT LOAD (resample_abs_pos_embed: class position apart, F.interpolate(size=, 'bicubic', antialias=True)).
+    The fixture is an HF CLIP vision model built NATIVELY for 592 x 592 whose position table is that resample, computed here
+    by the torch call timm makes; the product gets the 14 x 14 table and must do the resampling itself (host C++)."""
+    import torch.nn.functional as F
+    name = "vit_base_patch16_clip_224.openai"
+    w = dict(W.synth_clip_vit(87, name, depth=12))
+    pe = w["pos_embed"]
+    D = pe.shape[-1]
+    grid = F.interpolate(pe[:, 1:].reshape(1, 14, 14, D).permute(0, 3, 1, 2), size=(37, 37), mode="bicubic", antialias=True)
+    w592 = dict(w)
+    w592["pos_embed"] = torch.cat([pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, 37 * 37, D)], 1)
+    m = _hf_clip(w592, 12, 16, image_size=592)
+    hs = m.vision_model(pixel_values=W.synth_images(89, 1, 592)).last_hidden_state
+    out = m.visual_projection(m.vision_model.post_layernorm(hs))
+    save("clip_vit_hf_592", b16_cls=out[:, 0], b16_patch_sample=out[:, 1::9], b16_absmax=out.abs().max(),
+         pos_sample=w592["pos_embed"][0, ::17, ::3])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = refshim.load()
@@ -421,6 +442,7 @@ def main():
     if want("vit_hf12"): gen_vit_hf12()
     if want("vit_hf_variants"): gen_vit_hf_variants()
     if want("clip_hf"): gen_clip_hf()
+    if want("clip_hf_592"): gen_clip_hf_592()
 
 
 if __name__ == "__main__":
