@@ -41,6 +41,9 @@ namespace pio {
 #ifndef PIO_DEC_GEMM_WAVES
 #define PIO_DEC_GEMM_WAVES 2
 #endif
+#ifndef PIO_DEC_WAVES_RG1    // waves per k_dec_gemm workgroup at <= 16 prefixes (K = 768 GEMMs)
+#define PIO_DEC_WAVES_RG1 4
+#endif
 #ifndef PIO_DEC_WAVES_RG4    // waves per k_dec_gemm workgroup at 33..64 prefixes
 #define PIO_DEC_WAVES_RG4 8
 #endif
@@ -77,12 +80,23 @@ namespace pio {
 #ifndef PIO_LMHEAD_CG
 #define PIO_LMHEAD_CG 1
 #endif
+#ifndef PIO_DEC_LEAN_TICKET   // split-K slabs through agent-scope relaxed atomics (sc1 accesses) instead of release / acquire fences (round 4)
+#define PIO_DEC_LEAN_TICKET 1
+#endif
 
 static constexpr int DEC_MAX_COLGROUPS = 128;  // split-K counters / slabs: Nout <= 1024 at <= 128 prefixes, fc2's 24 x 4 tiles at 256 (kernels.h: DEC_SPLITK_*)
 static constexpr size_t DEC_SPLITK_WS_FLOATS = (size_t)DEC_SPLITK_COUNTERS * 4 * 8 * 256;   // api.cpp: splitk_ws
 static_assert(DEC_MAX_COLGROUPS == DEC_SPLITK_COUNTERS, "kernels.h");
 
 enum DecEpi { DE_STORE = 0, DE_RESID = 1, DE_GELU = 2, DE_EMBED = 3, DE_ARGMAX = 4 };
+
+// diagnostic build only (tools/microbench/dec_bench.hip stamps): shader-clock stamps of wave 0 of every k_dec_gemm workgroup
+#ifdef PIO_DEC_STAMPS
+__device__ unsigned long long g_dec_stamps[8][512][8];     // [kind = EPI + 4 (KS > 1)][workgroup][stamp]
+#define PIO_STAMP(i) do { if (threadIdx.x == 0) g_dec_stamps[(EPI & 3) + (KS > 1 ? 4 : 0)][(blockIdx.y * gridDim.x + blockIdx.x) & 511][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PIO_STAMP(i) do {} while (0)
+#endif
 
 __device__ __forceinline__ f32x4 mfma16f(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -111,12 +125,33 @@ __device__ __forceinline__ float row16_max(float v) {
   return v;
 }
 
+// A split-K partial tile crosses XCDs (each has its own L2).  Round 1 published it with an agent-scope RELEASE fence (an L2 write-back)
+// and read it behind an ACQUIRE fence (an L2 invalidate); tools/microbench/persist_probe.hip: the same exchange costs half as much when
+// the DATA itself moves by relaxed agent-scope atomic accesses (sc1 stores write through, sc1 loads read the coherent copy; 4.2 against
+// 8.0 us per all-to-all exchange, every value checked) and no fence is executed at all.  Order: slab stores -> s_waitcnt vmcnt(0) (written
+// through) -> workgroup barrier -> ticket; the last arrival's slab loads are issued after it has seen the ticket.
+__device__ __forceinline__ void st_agent(float* p, f32x4 v) {
+  typedef unsigned long long u64;
+  const u64 lo = (u64)__float_as_uint(v[0]) | ((u64)__float_as_uint(v[1]) << 32), hi = (u64)__float_as_uint(v[2]) | ((u64)__float_as_uint(v[3]) << 32);
+  __hip_atomic_store((u64*)p, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((u64*)p + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x4 ld_agent(const float* p) {
+  typedef unsigned long long u64;
+  const u64 lo = __hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi = __hip_atomic_load((const u64*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (f32x4){__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32))};
+}
+
 __device__ __forceinline__ float gelu_new(float x) {
   // transformers "gelu_new": 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
   return 0.5f * x * (1.0f + tanhf(u));
 }
 
+// (Round 4, measured and removed: extra workgroups per kernel that warm L2 with the NEXT kernel's weights -- lines do survive the kernel
+//  boundary and a same-XCD warm-up takes 1.0 us off a pure streaming consumer, tools/microbench/l2_prefetch_probe.hip -- gave 0.4-0.5 us on
+//  c_attn / c_fc, nothing on the others and 4.33 against 4.33 ms per decode: by the stamps below a layer GEMM spends 2.6 of its 5.5 us
+//  waiting for X, the previous kernel's output, to cross from the other XCDs' L2 through memory; the weights are not what it waits for.)
 // out[n][j] = epilogue( sum_k X[n][k] * W[j][k] )        W [Nout][K] ([out][in]), X [N][K]
 //   grid = (ceil(Nout/16), KS) workgroups of NWV waves; each wave owns CPW*16 k's: K = KS * NWV * CPW * 16
 //   (KS = 1: K = 768 or 512; KS = 4: K = 3072).  NWV = 4; 8 at more than 32 prefixes, where the X loads (all of
@@ -138,6 +173,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? PIO_DEC_GEMM_WAVES : 1) void k
   __shared__ __attribute__((aligned(16))) float red[NWV * RG * 256];
   __shared__ float s_sum[LN ? NWV : 1][RG * 16], s_sq[LN ? NWV : 1][RG * 16];
   __shared__ int s_last;
+  PIO_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int col0 = blockIdx.x * 16;
@@ -146,32 +182,49 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? PIO_DEC_GEMM_WAVES : 1) void k
   const int k0 = (blockIdx.y * NWV + wid) * (16 * CPW) + 4 * kq;
   const float* wp = W + (size_t)jc * K + k0;
   float4 w4[CPW];
-#pragma unroll
-  for (int c = 0; c < CPW; ++c) w4[c] = *(const float4*)(wp + 16 * c);       // the HBM stream: all in flight
-  __builtin_amdgcn_sched_barrier(0);   // keep hipcc from sinking the loads next to their MFMAs (2 in flight)
   f32x4 acc[RG];
-  constexpr bool XLDS = PIO_DEC_XLDS && RG == 1 && NWV == 4 && CPW == 12;      // the workgroup's K range: 768 columns of X
+  constexpr bool XLDS = PIO_DEC_XLDS && RG == 1 && NWV * CPW == 48;             // the workgroup's K range: 768 columns of X
   const int kbase = blockIdx.y * (NWV * 16 * CPW);
   __shared__ __attribute__((aligned(16))) float s_x[XLDS ? 16 * 772 : 4];
+  // Loads return in the order they were issued: the epilogue vectors first (three dwords, needed last), then X, whose staging through
+  // LDS then runs under the weight stream instead of behind it, then the weights.  Stamps of a layer GEMM at <= 16 prefixes
+  // (tools/microbench/dec_bench.hip built with -DPIO_DEC_STAMPS, shader cycles of wave 0, ~1.9 GHz): entry -> X landed and staged 5.4 k
+  // (2.7 us: the previous kernel's output has to cross from the other XCDs' L2 through memory; the same for the 2.4-MB attn.c_proj
+  // and the 9.4-MB c_fc, so it is latency, not the weight stream), fragment reads + 48 MFMAs 1.9 k, reduction 0.4-1.1 k, epilogue
+  // until the stores have landed 1.7-2.5 k; the split-K ticket of mlp.c_proj another 2.5 k.
+  const float bj = EPI == DE_ARGMAX && !LN ? 0.f : bias[jc];
+  const float cj = LN ? cvec[jc] : 0.f;
+  const float ej = EPI == DE_EMBED ? extra[jc] : 0.f;
   if constexpr (XLDS) {
     // <= 16 prefixes: the workgroup's slice of X (16 x 768) goes through LDS with fully coalesced loads instead of
     // 16-row x 64-B fragment-shaped ones (rows padded to 772 floats: the 16 rows of a fragment read fall on 16
     // distinct 16-B slots).  Same values, same MFMA order: bit-identical; 0.25-0.5 us per kernel.  (Above 16 prefixes,
     // one row group at a time with the next one prefetched: two barriers per group and a staging array that hipcc keeps
     // in scratch made it 2x slower -- 19.9 vs 9.9 us for qkv at 64 prefixes; not kept.)
-    float4 xs[12];
+    constexpr int NT = 64 * NWV, XI = 3072 / NT;
+    float4 xs[XI];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      const int e = tid + 256 * i, r = e / 192, c4 = e - r * 192;
+    for (int i = 0; i < XI; ++i) {
+      const int e = tid + NT * i, r = e / 192, c4 = e - r * 192;
       const int rc = r < N ? r : N - 1;
       xs[i] = *(const float4*)(X + (size_t)rc * K + kbase + 4 * c4);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      const int e = tid + 256 * i, r = e / 192, c4 = e - r * 192;
+    for (int c = 0; c < CPW; ++c) w4[c] = *(const float4*)(wp + 16 * c);       // the HBM stream: all in flight
+    __builtin_amdgcn_sched_barrier(0);   // keep hipcc from sinking the loads next to their MFMAs (2 in flight)
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int e = tid + NT * i, r = e / 192, c4 = e - r * 192;
       *(float4*)(s_x + r * 772 + 4 * c4) = xs[i];
     }
+    PIO_STAMP(1);
     __syncthreads();
+    PIO_STAMP(2);
+  } else {
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) w4[c] = *(const float4*)(wp + 16 * c);       // the HBM stream: all in flight
+    __builtin_amdgcn_sched_barrier(0);   // keep hipcc from sinking the loads next to their MFMAs (2 in flight)
   }
 #pragma unroll
   for (int g = 0; g < RG; ++g) {
@@ -213,19 +266,21 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? PIO_DEC_GEMM_WAVES : 1) void k
     }
 #undef PIO_XC
     acc[g] = a0 + a1;
+#ifdef PIO_DEC_STAMPS
+    asm volatile("s_nop 0" : "+v"(acc[g]));
+    PIO_STAMP(3);
+#endif
     if (LN) {   // row statistics of x: this lane holds 4*CPW values of row 16g+li; sum the 4 kq groups
       sx += __shfl_xor(sx, 16); sx += __shfl_xor(sx, 32);
       sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
       if (kq == 0) { s_sum[wid][g * 16 + li] = sx; s_sq[wid][g * 16 + li] = sq; }
     }
   }
-  // epilogue vectors: issued before the LDS reduction so their latency overlaps it
-  const float bj = EPI == DE_ARGMAX && !LN ? 0.f : bias[jc];
-  const float cj = LN ? cvec[jc] : 0.f;
-  const float ej = EPI == DE_EMBED ? extra[jc] : 0.f;
 #pragma unroll
   for (int g = 0; g < RG; ++g) *(f32x4*)(red + ((wid * RG + g) * 64 + lane) * 4) = acc[g];
   __syncthreads();
+  PIO_STAMP(4);
+  if constexpr (KS == 1) PIO_STAMP(5);
   f32x4 sums[(RG + NWV - 1) / NWV];
 #pragma unroll
   for (int gi = 0; gi < (RG + NWV - 1) / NWV; ++gi) {
@@ -242,31 +297,41 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? PIO_DEC_GEMM_WAVES : 1) void k
 #pragma unroll
     for (int gi = 0; gi < (RG + NWV - 1) / NWV; ++gi) {
       const int g = wid + NWV * gi;
-      if (g < RG) *(f32x4*)(slab + ((size_t)blockIdx.y * RG + g) * 256 + lane * 4) = sums[gi];
+      if (g < RG) {
+        float* sp = slab + ((size_t)blockIdx.y * RG + g) * 256 + lane * 4;
+        if constexpr (PIO_DEC_LEAN_TICKET) st_agent(sp, sums[gi]);
+        else *(f32x4*)sp = sums[gi];
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its stores
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the release's write-back has completed
+      if constexpr (!PIO_DEC_LEAN_TICKET) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the release's write-back has completed
+      }
       const unsigned t = __hip_atomic_fetch_add(cnt + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_last = (t == (unsigned)(KS - 1));
     }
     __syncthreads();
+    PIO_STAMP(5);
     if (!s_last) return;
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (!PIO_DEC_LEAN_TICKET) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __hip_atomic_store(cnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
     }
-    __syncthreads();
+    if constexpr (!PIO_DEC_LEAN_TICKET) __syncthreads();
 #pragma unroll
     for (int gi = 0; gi < (RG + NWV - 1) / NWV; ++gi) {
       const int g = wid + NWV * gi;
       if (g < RG) {
-        f32x4 s = *(const f32x4*)(slab + ((size_t)0 * RG + g) * 256 + lane * 4);
+        const float* sp = slab + (size_t)g * 256 + lane * 4;
+        f32x4 s = PIO_DEC_LEAN_TICKET ? ld_agent(sp) : *(const f32x4*)sp;
 #pragma unroll
-        for (int y = 1; y < KS; ++y) s += *(const f32x4*)(slab + ((size_t)y * RG + g) * 256 + lane * 4);
+        for (int y = 1; y < KS; ++y) s += PIO_DEC_LEAN_TICKET ? ld_agent(sp + (size_t)y * RG * 256) : *(const f32x4*)(sp + (size_t)y * RG * 256);
         sums[gi] = s;
       }
     }
@@ -328,6 +393,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? PIO_DEC_GEMM_WAVES : 1) void k
       }
     }
   }
+#ifdef PIO_DEC_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PIO_STAMP(6);
+#endif
 }
 
 // Causal attention for the new position `pos` of prefix n, head h: appends k,v to the cache and attends
@@ -482,10 +551,15 @@ template <int CPW, int KS, int EPI, int LN>
 static hipError_t dec_gemm_rg(const float* W, const float* X, int N, int Nout, int K, const float* bias, float* out,
                               const float* extra, const float* cvec, float eps, float* ws, unsigned* cnt,
                               hipStream_t s) {
-  const dim3 grid(ceil_div(Nout, 16), KS);
   const int rg = ceil_div(N, 16);
+  const dim3 grid(ceil_div(Nout, 16), KS);
 #define PIO_DG(R, C, NW) hipLaunchKernelGGL((k_dec_gemm<R, C, KS, EPI, LN, NW>), grid, dim3(64 * NW), 0, s, W, X, N, Nout, K, bias, out, extra, cvec, eps, ws, cnt)
-  if (rg <= 1) PIO_DG(1, CPW, 4);
+  if (rg <= 1) {
+    // <= 16 prefixes, K = 768: eight waves of 96 k each (round 4, -DPIO_DEC_WAVES_RG1=8) halve the MFMA chain (1.9 k -> 1.3 k cycles by the
+    // stamps) and lose it again in the reduction over eight partial tiles: 4.33 against 4.20-4.33 ms per decode, not the default
+    if constexpr (PIO_DEC_WAVES_RG1 == 8 && CPW == 12 && KS == 1 && EPI != DE_ARGMAX) PIO_DG(1, CPW / 2, 8);
+    else PIO_DG(1, CPW, 4);
+  }
   else if (rg <= 2) PIO_DG(2, CPW, 4);
   else if (rg <= 4) {
     if constexpr (PIO_DEC_WAVES_RG4 == 8 && CPW % 4 == 0 && EPI != DE_ARGMAX) PIO_DG(4, CPW / 2, 8);
@@ -679,27 +753,36 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_b(const float* __rest
     const int tile = blockIdx.z * gridDim.x + blockIdx.x;
     float* tbase = ws + (size_t)tile * KS * NP * 256;
     const int pr = cg * RGB + g;
-    if (fin) *(f32x4*)(tbase + ((size_t)blockIdx.y * NP + pr) * 256 + lane * 4) = s;
+    if (fin) {
+      float* sp = tbase + ((size_t)blockIdx.y * NP + pr) * 256 + lane * 4;
+      if constexpr (PIO_DEC_LEAN_TICKET) st_agent(sp, s);
+      else *(f32x4*)sp = s;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its stores
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the release's write-back has completed
+      if constexpr (!PIO_DEC_LEAN_TICKET) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the release's write-back has completed
+      }
       const unsigned t = __hip_atomic_fetch_add(cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_last = (t == (unsigned)(KS - 1));
     }
     __syncthreads();
     if (!s_last) return;
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (!PIO_DEC_LEAN_TICKET) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __hip_atomic_store(cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
     }
-    __syncthreads();
+    if constexpr (!PIO_DEC_LEAN_TICKET) __syncthreads();
     if (fin) {
-      s = *(const f32x4*)(tbase + ((size_t)0 * NP + pr) * 256 + lane * 4);
+      const float* sp = tbase + (size_t)pr * 256 + lane * 4;
+      s = PIO_DEC_LEAN_TICKET ? ld_agent(sp) : *(const f32x4*)sp;
 #pragma unroll
-      for (int y = 1; y < KS; ++y) s += *(const f32x4*)(tbase + ((size_t)y * NP + pr) * 256 + lane * 4);
+      for (int y = 1; y < KS; ++y) s += PIO_DEC_LEAN_TICKET ? ld_agent(sp + (size_t)y * NP * 256) : *(const f32x4*)(sp + (size_t)y * NP * 256);
     }
   }
   if (!fin) return;

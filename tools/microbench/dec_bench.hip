@@ -11,6 +11,11 @@ using namespace pio;
 
 __global__ void k_empty(float* p) { if (p == nullptr) *p = 0.f; }
 __global__ void k_touch(float* p) { p[blockIdx.x * 256 + threadIdx.x] += 1.0f; }
+__global__ __launch_bounds__(256) void k_touch_read(const float4* __restrict__ p, size_t n4, float* sink) {
+  float a = 0.f;
+  for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) { const float4 v = p[i]; a += v.x + v.y + v.z + v.w; }
+  if (a == 123.456f) *sink = a;
+}
 
 template <typename F>
 static float time_chain(F f, int iter = 200) {
@@ -54,6 +59,47 @@ int main(int argc, char** argv) {
   hipStream_t s = 0;
   int nblk = 0;
   printf("N=%d\n", N);
+#ifdef PIO_DEC_STAMPS
+  {  // where a layer GEMM's time goes, in situ: 30 "steps" of 4 layers (own weights each) + a 77-MB sweep standing in for the head
+    float *wq[4], *wp[4], *wf[4], *wg[4], *sweep;
+    for (int l = 0; l < 4; ++l) {
+      CK(hipMalloc(&wq[l], (size_t)3 * E * E * 4)); CK(hipMalloc(&wp[l], (size_t)E * E * 4)); CK(hipMalloc(&wf[l], (size_t)4 * E * E * 4)); CK(hipMalloc(&wg[l], (size_t)4 * E * E * 4));
+      CK(hipMemcpy(wq[l], h.data(), (size_t)3 * E * E * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(wp[l], h.data(), (size_t)E * E * 4, hipMemcpyHostToDevice));
+      CK(hipMemcpy(wf[l], h.data(), (size_t)4 * E * E * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(wg[l], h.data(), (size_t)4 * E * E * 4, hipMemcpyHostToDevice));
+    }
+    CK(hipMalloc(&sweep, (size_t)77 << 20)); CK(hipMemset(sweep, 0, (size_t)77 << 20));
+    auto step = [&] {
+      for (int l = 0; l < 4; ++l) {
+        dec_gemm<DE_STORE, 1>(wq[l], x, N, 3 * E, E, bias, qkv, nullptr, cvec, 1e-5f, nullptr, nullptr, s);
+        hipLaunchKernelGGL(k_dec_attention, dim3(N * heads), dim3(256), 0, s, qkv, kc, vc, E, heads, 15, S, att);
+        dec_gemm<DE_RESID, 0>(wp[l], att, N, E, E, bias, x, nullptr, nullptr, 0.f, nullptr, nullptr, s);
+        dec_gemm<DE_GELU, 1>(wf[l], x, N, 4 * E, E, bias, hid, nullptr, cvec, 1e-5f, nullptr, nullptr, s);
+        dec_gemm<DE_RESID, 0>(wg[l], hid, N, E, 4 * E, bias, x, nullptr, nullptr, 0.f, ws, cnt, s);
+      }
+      hipLaunchKernelGGL(k_touch_read, dim3(1024), dim3(256), 0, s, (const float4*)sweep, ((size_t)77 << 20) / 16, x);
+    };
+    hipStream_t cs; hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    const float us = time_chain(step, 30);
+    printf("emulated step (20 layer kernels + 77-MB sweep): %.1f us\n", us);
+    static unsigned long long st[8][512][8];
+    CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_dec_stamps), sizeof(st)));
+    const char* names[8] = {"qkv (store, LN)", "proj (resid)", "fc (gelu, LN)", "embed", "-", "fc2 (resid, split-K)", "-", "-"};
+    const int nwg[8] = {3 * E / 16, E / 16, 4 * E / 16, 0, 0, 4 * (E / 16), 0, 0};
+    for (int k = 0; k < 8; ++k) {
+      if (!nwg[k]) continue;
+      double d[7] = {0, 0, 0, 0, 0, 0, 0}; unsigned long long t0min = ~0ull, t6max = 0; int cntd = 0;
+      for (int b = 0; b < nwg[k] && b < 512; ++b) {
+        const unsigned long long* t = st[k][b];
+        if (t[6] < t[0] || t[6] == 0) continue;      // a workgroup that left early (not the last split-K arrival)
+        for (int i = 1; i < 7; ++i) if (t[i] >= t[i - 1] || i == 5) d[i] += (double)(t[i] > t[i - 1] ? t[i] - t[i - 1] : 0);
+        t0min = t[0] < t0min ? t[0] : t0min; t6max = t[6] > t6max ? t[6] : t6max; ++cntd;
+      }
+      if (!cntd) continue;
+      printf("  %-22s stamps (100-MHz ticks x10 ns or shader cycles, mean over %3d wg): issue->X staged %6.0f | barrier %6.0f | reads+MFMA %6.0f | reduce barrier %6.0f | ticket %6.0f | epilogue+stores landed %6.0f | first entry -> last exit %6.0f\n",
+             names[k], cntd, d[1] / cntd, d[2] / cntd, d[3] / cntd, d[4] / cntd, d[5] / cntd, d[6] / cntd, (double)(t6max - t0min));
+    }
+  }
+#endif
   printf("empty kernel       %7.2f us\n", time_chain([&] { hipLaunchKernelGGL(k_empty, dim3(64), dim3(256), 0, s, x); }, 1000));
   printf("touch kernel (RMW) %7.2f us\n", time_chain([&] { hipLaunchKernelGGL(k_touch, dim3(48), dim3(256), 0, s, x); }, 1000));
   {  // the same two kernels replayed from a graph of 200 nodes (what the decode loop uses)
