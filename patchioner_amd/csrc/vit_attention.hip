@@ -161,119 +161,108 @@ __global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAt
   PIO_LOAD_KV(0);
   PIO_STORE_KV(0);
   __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
+  typedef typename Vec2<T>::type half2_t;
+  // One 64-key tile.  NKB = key blocks of 32 that hold keys of the sequence (2, or 1 in a last tile with <= 32 keys left), MASKED =
+  // the tile holds padding (only a sequence's last tile does).  Round 4: the tile with padding is a code path of its own, entered by
+  // a scalar branch (`left` is block-uniform), so full tiles carry no mask code and a short last tile -- T = 261 leaves 5 keys, 518^2
+  // leaves 30 -- multiplies 32 keys instead of 64 for S^T and only the 16-key steps that hold keys for O^T.  The skipped products
+  // are exact zeros of the long form (masked scores give p = 0; padded V^T rows are zero), so the bits do not change.  Same live
+  // registers as before (round 3's skip inside the one loop body cost 4 VGPRs and with them a wave per SIMD).
+#define PIO_ATTN_TILE(NKB, MASKED, NS2)                                                                                   \
+  do {                                                                                                                \
+    f32x16 st[NKB];                                                                                                   \
+    _Pragma("unroll") for (int kbk = 0; kbk < NKB; ++kbk) {                                                           \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) st[kbk][r] = 0.f;                                                \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                 \
+        const frag_t kf = *(const frag_t*)(sk + (kbk * 32 + r31) * 128 + (((2 * s + h) ^ sw7) << 4));                 \
+        st[kbk] = mfma32(kf, qf[s], st[kbk]);                                                                         \
+      }                                                                                                               \
+    }                                                                                                                 \
+    if (MASKED) {                                                                                                     \
+      _Pragma("unroll") for (int kbk = 0; kbk < NKB; ++kbk)                                                           \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                \
+          if (kbk * 32 + acc_row32(r, lane) >= left) st[kbk][r] = -1e30f;                                             \
+    }                                                                                                                 \
+    float mx = st[0][0];                                                                                              \
+    _Pragma("unroll") for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[0][r]);                                          \
+    if (NKB == 2) { _Pragma("unroll") for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[NKB - 1][r]); }                  \
+    mx = xor32_max(mx);                                /* v_permlane32_swap: no LDS crossbar round trip on the chain */ \
+    const float m_new = fmaxf(m_run, mx * sl2);                                                                       \
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {                                                           \
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                                                      \
+      l_run *= alpha;                                                                                                 \
+      const f32x2 av = {alpha, alpha};                                                                                \
+      _Pragma("unroll") for (int d = 0; d < 2; ++d)                                                                   \
+        _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                                           \
+          f32x2 o = {ot[d][r], ot[d][r + 1]};                                                                         \
+          o *= av;                                                                                                    \
+          ot[d][r] = o[0]; ot[d][r + 1] = o[1];                                                                       \
+        }                                                                                                             \
+      m_run = m_new;                                                                                                  \
+    }                                                                                                                 \
+    /* plain (un-packed) fp32 VALU: v_pk_fma_f32 / v_pk_add_f32 do not run beside another wave's MFMAs on gfx950, plain */ \
+    /* v_fma_f32 / v_add_f32 do (tools/microbench/mfma_valu_overlap2.hip), and three waves share a SIMD here */       \
+    float rs_a = 0.f, rs_b = 0.f;                                                                                     \
+    half2_t ph[NKB][8];                                                                                               \
+    const float nm = -m_run;                                                                                          \
+    _Pragma("unroll") for (int kbk = 0; kbk < NKB; ++kbk)                                                             \
+      _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                                             \
+        float z0, z1;                                                                                                 \
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(z0) : "v"(st[kbk][r]), "v"(sl2), "v"(nm));                              \
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(z1) : "v"(st[kbk][r + 1]), "v"(sl2), "v"(nm));                          \
+        f32x2 p;                                                                                                      \
+        p[0] = __builtin_amdgcn_exp2f(z0);                                                                            \
+        p[1] = __builtin_amdgcn_exp2f(z1);                                                                            \
+        /* s_nop: the operand is a transcendental's result (v_exp_f32), which needs one wait state before a VALU reads it; hipcc */ \
+        /* inserts it for its own instructions, not for inline asm (round 4: found as run-to-run differences once it scheduled */ \
+        /* the add right behind the exponential) */                                                                     \
+        asm("s_nop 0\n\tv_add_f32 %0, %0, %1" : "+v"(rs_a) : "v"(p[0]));                                               \
+        asm("s_nop 0\n\tv_add_f32 %0, %0, %1" : "+v"(rs_b) : "v"(p[1]));                                               \
+        ph[kbk][r >> 1] = __builtin_convertvector(p, half2_t);                                                        \
+      }                                                                                                               \
+    float rs = rs_a + rs_b;                                                                                           \
+    rs = xor32_add(rs);                                                                                               \
+    l_run += rs;                                                                                                      \
+    /* O^T += V^T . P^T */                                                                                            \
+    _Pragma("unroll") for (int kbk = 0; kbk < NKB; ++kbk) {                                                           \
+      _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                              \
+        if (s2 < (NS2)) {                                                                                             \
+          frag_t pf;                                                                                                  \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) { pf[2 * j] = ph[kbk][4 * s2 + j][0]; pf[2 * j + 1] = ph[kbk][4 * s2 + j][1]; } \
+          _Pragma("unroll") for (int d = 0; d < 2; ++d) {                                                             \
+            const frag_t vf = *(const frag_t*)(sv + (d * 32 + r31) * 128 + (((4 * kbk + 2 * s2 + h) ^ sw7) << 4));    \
+            ot[d] = mfma32(vf, pf, ot[d]);                                                                            \
+          }                                                                                                           \
+        }                                                                                                             \
+      }                                                                                                               \
+    }                                                                                                                 \
+  } while (0)
+  // every tile but the last is full: no padding, no mask
+  for (int kt = 0; kt + 1 < nkt; ++kt) {
     const int buf = kt & 1;
-    const int ktn = kt + 1 < nkt ? kt + 1 : kt;   // the last iteration reloads its own tile (never stored)
-    PIO_LOAD_KV(ktn);
+    constexpr int left = KV_TILE;
+    PIO_LOAD_KV(kt + 1);
     if (active) {
       const char* sk = smem + buf * 2 * KV_TILE_BYTES;
       const char* sv = sk + KV_TILE_BYTES;
-      f32x16 st[2];
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[kbk][r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const frag_t kf = *(const frag_t*)(sk + (kbk * 32 + r31) * 128 + (((2 * s + h) ^ sw7) << 4));
-          st[kbk] = mfma32(kf, qf[s], st[kbk]);
-        }
-      }
-      // the lean softmax: padding keys are masked only in the sequence's last tile; the scale rides in the exponent's FMA (the
-      // maximum is taken over raw scores); packed conversions; no rescale while no query's maximum moved.
-      // (Skipping the all-padding upper half of a sequence's last tile as well costs 4 more VGPRs -- 172, two waves per SIMD
-      // instead of three -- and loses: 53.6 against 47.8 us at 64 images.)
-      const int left = nkeys - kt * KV_TILE;              // keys of the sequence in this tile and after (block-uniform)
-      if (left < KV_TILE) {
-#pragma unroll
-        for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (kbk * 32 + acc_row32(r, lane) >= left) st[kbk][r] = -1e30f;
-      }
-      float mx = st[0][0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[0][r]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[1][r]);
-      mx = xor32_max(mx);                                // v_permlane32_swap: no LDS crossbar round trip on the chain
-      const float m_new = fmaxf(m_run, mx * sl2);
-      if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= alpha;
-        const f32x2 av = {alpha, alpha};
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            f32x2 o = {ot[d][r], ot[d][r + 1]};
-            o *= av;
-            ot[d][r] = o[0]; ot[d][r + 1] = o[1];
-          }
-        m_run = m_new;
-      }
-#if PIO_ATTN_PLAIN_VALU
-      // plain (un-packed) fp32 VALU: v_pk_fma_f32 / v_pk_add_f32 do not run beside another wave's MFMAs on gfx950, plain
-      // v_fma_f32 / v_add_f32 do (tools/microbench/mfma_valu_overlap2.hip), and three waves share a SIMD here
-      float rs_a = 0.f, rs_b = 0.f;
-      typedef typename Vec2<T>::type half2_t;
-      half2_t ph[2][8];
-      const float nm = -m_run;
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          float z0, z1;
-          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(z0) : "v"(st[kbk][r]), "v"(sl2), "v"(nm));
-          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(z1) : "v"(st[kbk][r + 1]), "v"(sl2), "v"(nm));
-          f32x2 p;
-          p[0] = __builtin_amdgcn_exp2f(z0);
-          p[1] = __builtin_amdgcn_exp2f(z1);
-          asm("v_add_f32 %0, %0, %1" : "+v"(rs_a) : "v"(p[0]));
-          asm("v_add_f32 %0, %0, %1" : "+v"(rs_b) : "v"(p[1]));
-          ph[kbk][r >> 1] = __builtin_convertvector(p, half2_t);
-        }
-      const f32x2 rs2 = {rs_a, rs_b};
-#else
-      const f32x2 sl2v = {sl2, sl2}, mv = {m_run, m_run};
-      f32x2 rs2 = {0.f, 0.f};
-      typedef typename Vec2<T>::type half2_t;
-      half2_t ph[2][8];
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2 sv2 = {st[kbk][r], st[kbk][r + 1]};
-          const f32x2 z = __builtin_elementwise_fma(sv2, sl2v, -mv);
-          f32x2 p;
-          p[0] = __builtin_amdgcn_exp2f(z[0]);
-          p[1] = __builtin_amdgcn_exp2f(z[1]);
-          rs2 += p;
-          ph[kbk][r >> 1] = __builtin_convertvector(p, half2_t);
-        }
-#endif
-      float rs = rs2[0] + rs2[1];
-      rs = xor32_add(rs);
-      l_run += rs;
-      // O^T += V^T . P^T
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          frag_t pf;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { pf[2 * j] = ph[kbk][4 * s2 + j][0]; pf[2 * j + 1] = ph[kbk][4 * s2 + j][1]; }
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            const frag_t vf = *(const frag_t*)(sv + (d * 32 + r31) * 128 + (((4 * kbk + 2 * s2 + h) ^ sw7) << 4));
-            ot[d] = mfma32(vf, pf, ot[d]);
-          }
-        }
-      }
+      PIO_ATTN_TILE(2, false, 2);
     }
-    PIO_STORE_KV(buf ^ 1);   // harmless on the last iteration: that buffer is not read again
+    PIO_STORE_KV(buf ^ 1);
     __syncthreads();
   }
+  if (active) {
+    const int kt = nkt - 1;
+    const char* sk = smem + (kt & 1) * 2 * KV_TILE_BYTES;
+    const char* sv = sk + KV_TILE_BYTES;
+    const int left = nkeys - kt * KV_TILE;              // keys of the sequence in the last tile (block-uniform; <= 0: an empty sequence)
+    if (left >= KV_TILE) PIO_ATTN_TILE(2, false, 2);
+    else if (left > 32) PIO_ATTN_TILE(2, true, 2);
+    else {
+      const int ns2 = left > 16 ? 2 : 1;                  // 16-key steps of O^T that hold keys
+      PIO_ATTN_TILE(1, true, ns2);
+    }
+  }
+#undef PIO_ATTN_TILE
 #undef PIO_LOAD_KV
 #undef PIO_STORE_KV
 

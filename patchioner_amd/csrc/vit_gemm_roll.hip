@@ -93,8 +93,10 @@ __device__ __forceinline__ float gelu_erf_plain(float v) {
   q = fma_plain(q, u, 4.590671448e-01f);
   q = fma_plain(q, u, 1.151118979e+00f);
   e = fma_plain(u, q, 1.0f);
-  asm("v_exp_f32 %0, -%1" : "=v"(e) : "v"(e));
-  hh = mul_plain(v, e);
+  // one statement: a VALU that reads a transcendental's result needs a wait state in between, which hipcc inserts for its own
+  // instructions and not for inline asm (round 4: vit_attention.hip produced run-to-run differences when the scheduler happened to
+  // put such a pair back to back; here it never had, by luck)
+  asm("v_exp_f32 %0, -%2\n\ts_nop 0\n\tv_mul_f32 %1, %3, %0" : "=&v"(e), "=v"(hh) : "v"(e), "v"(v));
   asm("v_max_f32 %0, %1, 0" : "=v"(m) : "v"(v));
   asm("v_sub_f32 %0, %1, |%2|" : "=v"(r) : "v"(m), "v"(hh));
   return r;
