@@ -25,6 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # Kernel arguments in device memory (a ROCm launch-latency setting, read when the HIP runtime initialises; never over the user's):
 # +1.2 % captions/s through the pipeline on one box, two alternations (8.58 against 8.47 k), nothing on the synchronous forward.
+# The same default as patchioner_amd/__init__.py and tests/conftest.py; the effective value is reported in `config.env`.
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import torch  # noqa: E402
@@ -73,8 +74,8 @@ def _stats(xs):
 
 def cpu_baseline():
     """The oracle (a port of the reference's algorithm as executed: no KV cache, 3-pass projection, python loops) timed on
-    this box's host cores: the bench workload (config 2: batch 16, traces) on all cores, 3 timed steps; the
-    same on ONE thread on a bounded sample (1 image); and BASELINE config 1 (4 images, caption_from=cls), 3 timed steps."""
+    this box's host cores: the bench workload (config 2: batch 16, traces) on all cores, 3 full-batch warm-up passes and
+    10 timed steps; the same on ONE thread on a bounded sample (1 image); and BASELINE config 1 (4 images, caption_from=cls), 10 timed steps."""
     import golden_cases as gc
     import numpy as np
     from oracle import patchioner_oracle as O
@@ -99,8 +100,8 @@ def cpu_baseline():
     imgs = W.synth_images(1, BATCH, CROP)
     rng = np.random.RandomState(2)
     traces = [gc.block_trace(int(rng.randint(0, 13)), int(rng.randint(0, 13))) for _ in range(BATCH)]
-    for _ in range(3):                                              # >= 3 warm-up passes: thread pools, allocations
-        m.forward(imgs[:2], get_cls_capt=False, traces=traces[:2])
+    for _ in range(3):                                              # >= 3 full-batch warm-up passes: thread pools, allocations
+        m.forward(imgs, get_cls_capt=False, traces=traces)
 
     def timed(fn, n):
         ts = []
@@ -110,17 +111,16 @@ def cpu_baseline():
             ts.append(time.perf_counter() - t0)
         return ts
 
-    t_all = timed(lambda: m.forward(imgs, get_cls_capt=False, traces=traces), 3)
+    t_all = timed(lambda: m.forward(imgs, get_cls_capt=False, traces=traces), 10)   # >= 10 timed steps: ~27 s
     t_c1 = timed(lambda: m.forward(imgs[:4], get_cls_capt=True), 10)       # BASELINE config 1: ~0.9 s a step, 10 timed steps
     torch.set_num_threads(1)
     t_one = timed(lambda: m.forward(imgs[:1], get_cls_capt=False, traces=traces[:1]), 1)
     torch.set_num_threads(cores)
-    med = sorted(t_all)[1]
+    med = sorted(t_all)[len(t_all) // 2]
     return {"value": BATCH / med, "unit": "captions/s", "cores": cores, "kind": "port",
-            "sample": "3 timed steps of the same workload (batch 16, 224^2, 12-layer ViT-B/14, 591753x768 fp32 bank, 30-step "
-                      "cache-less decode) on torch-CPU fp32 after 3 warm-up passes (2 images each): %s s (~2.7 s each: the bounded "
-                      "10-30 s sample); value = 16 / median"
-                      % ", ".join("%.1f" % t for t in t_all),
+            "sample": "10 timed steps of the same workload (batch 16, 224^2, 12-layer ViT-B/14, 591753x768 fp32 bank, 30-step "
+                      "cache-less decode) on torch-CPU fp32 after 3 full-batch warm-up passes: %s s (the bounded ~30 s sample); "
+                      "value = 16 / median" % ", ".join("%.1f" % t for t in t_all),
             "samples_s": t_all,
             "one_thread": {"value": 1.0 / t_one[0], "unit": "captions/s", "cores": 1,
                            "sample": "1 step of 1 image / 1 trace (bounded sample), %.1f s" % t_one[0]},
@@ -422,9 +422,12 @@ def main():
                              "device-resident images, id->string included; %d calls, each timed" % sync_steps},
             "pipelined_groups": {"ms_per_group": group_stats, "batches_per_group": P,
                                  "captions_per_s_at_median": BATCH * P * world * 1e3 / group_stats["median"]} if group_stats else None,
-            "config": {"workload": "talk2dino_decap_COCO, ViT-B/14-reg 224^2, batch 16/GPU, caption_from=patches "
+            "config": {"workload": ("config 2, bs16 traces; value: %d images per ViT launch, %d prefixes per decode (pipeline API); forward_sync: "
+                                    "1 forward(16) per call. " % (BATCH * VB, BATCH * P) if pipe is not None else "config 2, bs16 traces, one forward(16) per step. ") +
+                                   "talk2dino_decap_COCO, ViT-B/14-reg 224^2, batch 16/GPU, caption_from=patches "
                                    "(one 16-patch trace region per image), bank 591753x768 fp32, 30-step greedy decode; `value` is measured "
                                    "through the throughput API (value_api), the drop-in forward() figure is forward_sync",
+                       "env": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
                        "arithmetic": {"vit": "fp16 operands, fp32 accumulation (v_mfma_f32_32x32x16_f16), fp32 residual stream / LayerNorm",
                                       "projection": "operands as fp16 hi + lo pairs (22 significant bits) on v_mfma_f32_16x16x32_f16, fp32 "
                                                     "accumulation and soft-max; as close to fp64 as an fp32 evaluation (DESIGN.md section 3)",

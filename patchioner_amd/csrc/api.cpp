@@ -132,7 +132,7 @@ struct pio_context {
   struct PKey { int N, P, steps; bool operator<(const PKey& o) const { return N != o.N ? N < o.N : (P != o.P ? P < o.P : steps < o.steps); } };
   // prompted-decode graphs, keyed by (rows, prompt positions, steps).  The prompt length follows the hard prompt of every batch,
   // so a long run meets many keys: the cache is a small LRU (a graph is ~ (P + steps) x 60 kernel nodes) and evicted execs are destroyed.
-  struct PGraph { hipGraphExec_t exec; uint64_t last_use; };
+  struct PGraph { hipGraphExec_t exec; uint64_t last_use; hipStream_t last_stream; };
   std::map<PKey, PGraph> pgraphs;
   uint64_t pgraph_clock = 0;
   static constexpr size_t kMaxPGraphs = 12;
@@ -1282,7 +1282,11 @@ static DecoderArgs lm_args(pio_context* c, int N) {
 static int beam_scratch(pio_context* c) {
   if (c->beam_stats) return PIO_OK;
   int rc;
-  const size_t kv = (size_t)c->cfg.dec_layers * c->cfg.max_prefixes * c->cfg.max_steps * c->cfg.dec_embd;
+  // pio_lm_prefill / pio_lm_advance take at most 16 rows (the beams of one image) and k_kv_gather indexes [layer][a.N][max_steps][E]:
+  // 16 rows of scratch, not max_prefixes (ViECap defaults: 0.3 GB for both instead of 2.4 GB).  Allocated on the first beam call
+  // (a hipMalloc: it synchronises the device once).
+  const size_t rows = c->cfg.max_prefixes < 16 ? c->cfg.max_prefixes : 16;
+  const size_t kv = (size_t)c->cfg.dec_layers * rows * c->cfg.max_steps * c->cfg.dec_embd;
   if ((rc = c->dmalloc(&c->beam_k, kv))) return rc;
   if ((rc = c->dmalloc(&c->beam_v, kv))) return rc;
   return c->dmalloc(&c->beam_stats, (size_t)2 * 16);
@@ -1390,13 +1394,15 @@ int pio_viecap_decode(pio_handle c, const float* cont, const int32_t* tokens, in
         auto old = c->pgraphs.begin();
         for (auto jt = c->pgraphs.begin(); jt != c->pgraphs.end(); ++jt)
           if (jt->second.last_use < old->second.last_use) old = jt;
-        HIP_OK(hipStreamSynchronize(s));                         // it may still be running on the caller's stream
+        HIP_OK(hipStreamSynchronize(old->second.last_stream));   // it may still be running on the stream it was last launched on
+        if (old->second.last_stream != s) HIP_OK(hipStreamSynchronize(s));
         (void)hipGraphExecDestroy(old->second.exec);
         c->pgraphs.erase(old);
       }
-      it = c->pgraphs.emplace(key, pio_context::PGraph{exec, 0}).first;
+      it = c->pgraphs.emplace(key, pio_context::PGraph{exec, 0, s}).first;
     }
     it->second.last_use = ++c->pgraph_clock;
+    it->second.last_stream = s;
     HIP_OK(hipGraphLaunch(it->second.exec, s));
   } else {
     HIP_OK(launch_decode_prompted(a, c->prompt_buf, P, s));

@@ -108,6 +108,18 @@ def _last_ids(model, steps: int) -> torch.Tensor:
     return ids
 
 
+def _all_ranks_ok(ok: bool, what: str, group=None) -> None:
+    """A failure on SOME ranks must fail EVERY rank before the collective that follows: a rank with an empty shard would otherwise
+    sit in all_gather waiting for ranks that have already raised.  One 1-element MIN all-reduce (gloo: on the CPU)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                            device="cpu" if dist.get_backend(group) == "gloo" else torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = bool(int(flag[0]))
+    if not ok:
+        raise RuntimeError("%s failed on at least one rank" % what)
+
+
 def sharded_trace_captions(model, imgs: torch.Tensor, traces: Sequence, detokenize, group=None, **fwd) -> List[str]:
     """Caption a global batch: every rank receives the same (imgs, traces), processes its contiguous shard
     with `model(...)` and all ranks return the captions of the whole batch in the original order."""
@@ -115,11 +127,14 @@ def sharded_trace_captions(model, imgs: torch.Tensor, traces: Sequence, detokeni
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     s, e = shard_bounds(imgs.shape[0], world, rank)
     steps = _id_columns(model)
+    ids, err = torch.zeros(0, steps, dtype=torch.int32, device=imgs.device), None
     if e > s:
-        model(imgs[s:e], get_cls_capt=False, traces=list(traces[s:e]), **fwd)
-        ids = _last_ids(model, steps)
-    else:
-        ids = torch.zeros(0, steps, dtype=torch.int32, device=imgs.device)
+        try:
+            model(imgs[s:e], get_cls_capt=False, traces=list(traces[s:e]), **fwd)
+            ids = _last_ids(model, steps)
+        except Exception as ex:          # noqa: BLE001 -- re-raised below, on every rank, before anyone enters the gather
+            err = ex
+    _all_ranks_ok(err is None, "sharded_trace_captions: the shard's forward (%r)" % (err,), group)
     all_ids = all_gather_ids(ids, group)
     return detokenize(all_ids.cpu().tolist())
 
@@ -135,11 +150,14 @@ def sharded_box_captions(model, imgs: torch.Tensor, bboxes: torch.Tensor, detoke
     B, NB = bboxes.shape[0], bboxes.shape[1]
     s, e = shard_bounds(B, world, rank)
     steps = _id_columns(model)
+    ids, err = torch.zeros(0, steps, dtype=torch.int32, device=imgs.device), None
     if e > s:
-        model(imgs[s:e], get_cls_capt=False, bboxes=bboxes[s:e], **fwd)       # a view: the in-place // patch_size reaches the caller
-        ids = _last_ids(model, steps)
-    else:
-        ids = torch.zeros(0, steps, dtype=torch.int32, device=imgs.device)
+        try:
+            model(imgs[s:e], get_cls_capt=False, bboxes=bboxes[s:e], **fwd)       # a view: the in-place // patch_size reaches the caller
+            ids = _last_ids(model, steps)
+        except Exception as ex:          # noqa: BLE001 -- re-raised below, on every rank, before anyone enters the gather
+            err = ex
+    _all_ranks_ok(err is None, "sharded_box_captions: the shard's forward (%r)" % (err,), group)
     flat = detokenize(all_gather_ids(ids, group).cpu().tolist())
     if fwd.get("get_controllable_capts"):
         return flat                           # one caption per image (model.py:1042-1047)

@@ -155,17 +155,28 @@ class TraceCaptionPipeline:
         probe = torch.cuda.Stream(priority=priority)
         wall([probe])                                         # warm
         base = min(wall([probe]) for _ in range(3))
-        chosen, spare = [], []
+        chosen, spare, ratios = [], [], []
         for cand in [probe] + [None] * candidates:
             if len(chosen) == n:
                 break
             cand = cand if cand is not None else torch.cuda.Stream(priority=priority)
             if any(cand.cuda_stream == c.cuda_stream for c in chosen + spare):
                 continue                                      # the pool has wrapped around
-            if min(wall(beside + chosen + [cand]) for _ in range(2)) < 1.45 * base:
+            ratio = min(wall(beside + chosen + [cand]) for _ in range(2)) / base
+            ratios.append(round(ratio, 2))
+            if ratio < 1.45:
                 chosen.append(cand)
             else:
                 spare.append(cand)
+        # what was decided, for whoever wonders about a run-dependent throughput (a busy device can make the probe misjudge): kept on the
+        # object and, with PIO_PIPELINE_LOG=1, printed
+        self.stream_probe = {"wanted": n, "concurrent": len(chosen), "fallback_shared_queue": max(0, n - len(chosen)),
+                             "ratios_to_one_stream": ratios, "base_ms": round(base * 1e3, 3)}
+        if len(chosen) < n or os.environ.get("PIO_PIPELINE_LOG") == "1":
+            import sys
+            print("patchioner_amd.pipeline: %d of %d decode streams run beside the stage stream(s); %d share a hardware queue "
+                  "(probe ratios %s, one spin %.3f ms)%s" % (len(chosen), n, max(0, n - len(chosen)), ratios, base * 1e3,
+                  "" if len(chosen) == n else " -- set GPU_MAX_HW_QUEUES=8 or use fewer decode clones"), file=sys.stderr)
         return chosen + spare[:n - len(chosen)]               # not enough independent queues: take what there is
 
     def _make_stream(self, n_cus, from_top: bool = False, priority: int = 0):

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # the configuration patchioner_amd/__init__.py and bench.py run (see there)
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -79,6 +79,19 @@ def _worker(rank, world, port, n_imgs, q):
     for k, g in enumerate(got):
         exp = [torch.full((2 + k + r, 30), 100 * r + k, dtype=torch.int32) for r in range(world) if k < 2 + r]
         assert torch.equal(g, torch.cat(exp)), k
+    # a model that leaves no ids on ONE rank (n_imgs = 1: the other rank's shard is empty): every rank raises before the gather,
+    # nobody waits in a collective for a rank that has already failed
+    class _Broken(_FakeModel):
+        def __call__(self, *a, **k):
+            super().__call__(*a, **k)
+            self.last_ids = None
+
+    try:
+        pdist.sharded_trace_captions(_Broken(), imgs, traces, lambda ids: ids)
+        raised = False
+    except RuntimeError as ex:
+        raised = "at least one rank" in str(ex)
+    assert raised
     if rank == 0:
         q.put(len(caps))
     dist.barrier()
