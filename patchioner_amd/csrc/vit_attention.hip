@@ -26,7 +26,7 @@
 // hipcc.  tools/microbench/mfma_valu_overlap2.hip (opcodes pinned): plain v_fma_f32 / v_add_f32 / v_cvt_pk DO overlap another
 // wave's MFMAs, v_pk_fma_f32 / v_pk_add_f32 do NOT.  The FMAs and adds of the softmax are therefore plain instructions
 // (PIO_ATTN_PLAIN_VALU): 43.0 us at 64 images against 44.8 packed, same bits.
-// k_vit_attention2 (tools/microbench/attic/vit_attention2.hip since round 3) was a larger restructuring built before that was understood; correct (same tests), not
+// k_vit_attention2 (removed from the tree in round 4; git history: tools/microbench/attic/vit_attention2.hip) was a larger restructuring built before that was understood; correct (same tests), not
 // faster, kept for its measurements:
 //   * workgroup = ceil(nq / ceil(nq / 8)) waves (T = 261: 9 query tiles = two workgroups of 5 waves instead of three of 4
 //     whose third is 6 % full); K / V^T by LDS-DMA through a ring of 2-4 tiles with counted vmcnt (no staging registers, no

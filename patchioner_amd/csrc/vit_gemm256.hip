@@ -21,7 +21,7 @@
 // barriers the two wave groups run different programs: waves 0-3 the 8 MFMAs of phase k (operands read in the interval before),
 // then the fragment reads of phase k + 1 and the LDS-DMA issue; waves 4-7 the reads of phase k, the LDS-DMA, then the MFMAs of
 // phase k -- so on every SIMD one wave multiplies while its partner reads.  (Round 2's first schedule, two barriers per phase
-// with the second group one segment behind, measured 1-4 % slower and lives in tools/microbench/attic/ since round 3.)
+// with the second group one segment behind, measured 1-4 % slower and was removed from the tree in round 4: git history, tools/microbench/attic/.)
 #include "common.h"
 #include "kernels.h"
 

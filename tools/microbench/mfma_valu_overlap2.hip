@@ -10,7 +10,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-enum { V_FMA = 1, V_PKFMA = 2, V_EXP = 3, V_CVTPK = 4, V_ADD = 5, V_MOV = 6 };
+enum { V_FMA = 1, V_PKFMA = 2, V_EXP = 3, V_CVTPK = 4, V_ADD = 5, V_MOV = 6, V_PKFMA16 = 7, V_EXP16 = 8, V_PKMAX16 = 9 };   // 7-9: round 4 (packed / transcendental fp16)
 
 template <int KIND>
 __device__ __forceinline__ void valu8(float (&v)[8], f32x2 (&p)[4]) {
@@ -21,6 +21,9 @@ __device__ __forceinline__ void valu8(float (&v)[8], f32x2 (&p)[4]) {
     else if (KIND == V_MOV) asm volatile("v_mov_b32 %0, %1" : "+v"(v[j]) : "v"(v[(j + 1) & 7]));
     else if (KIND == V_EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(v[j]));
     else if (KIND == V_CVTPK) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(v[j]) : "v"(v[(j + 1) & 7]));
+    else if (KIND == V_PKFMA16) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(v[j]) : "v"(v[(j + 1) & 7]), "v"(v[(j + 2) & 7]));
+    else if (KIND == V_EXP16) asm volatile("v_exp_f16 %0, %0" : "+v"(v[j]));
+    else if (KIND == V_PKMAX16) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(v[j]) : "v"(v[(j + 1) & 7]));
     else if (KIND == V_PKFMA) { if (j < 4) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[j]) : "v"(p[(j + 1) & 3]), "v"(p[(j + 2) & 3])); }
   }
 }
@@ -76,6 +79,8 @@ __global__ __launch_bounds__(256) void k_same(float* out, int iters) {
         else if (KIND == V_PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[j & 3]) : "v"(p[(j + 1) & 3]), "v"(p[(j + 2) & 3]));
         else if (KIND == V_EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(v[j & 7]));
         else if (KIND == V_CVTPK) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(v[j & 7]) : "v"(v[(j + 1) & 7]));
+        else if (KIND == V_PKFMA16) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(v[j & 7]) : "v"(v[(j + 1) & 7]), "v"(v[(j + 2) & 7]));
+        else if (KIND == V_EXP16) asm volatile("v_exp_f16 %0, %0" : "+v"(v[j & 7]));
       }
     }
   }
@@ -118,6 +123,10 @@ int main() {
   cross<V_MOV>("v_mov_b32", out, iters, 32);
   cross<V_PKFMA>("v_pk_fma_f32", out, iters, 16);
   cross<V_EXP>("v_exp_f32", out, iters, 32);
+  cross<V_PKFMA16>("v_pk_fma_f16", out, iters, 32);
+  cross<V_PKMAX16>("v_pk_max_f16", out, iters, 32);
+  cross<V_EXP16>("v_exp_f16", out, iters, 32);
+  same<V_PKFMA16, 2>("v_pk_fma_f16", out, iters); same<V_PKFMA16, 4>("v_pk_fma_f16", out, iters); same<V_PKFMA16, 6>("v_pk_fma_f16", out, iters);
   cross<V_CVTPK>("v_cvt_pk_f16", out, iters, 32);
   same<V_FMA, 0>("v_fma_f32", out, iters);
   same<V_FMA, 2>("v_fma_f32", out, iters);
