@@ -151,7 +151,11 @@ __device__ __forceinline__ float gelu_new(float x) {
 // (Round 4, measured and removed: extra workgroups per kernel that warm L2 with the NEXT kernel's weights -- lines do survive the kernel
 //  boundary and a same-XCD warm-up takes 1.0 us off a pure streaming consumer, tools/microbench/l2_prefetch_probe.hip -- gave 0.4-0.5 us on
 //  c_attn / c_fc, nothing on the others and 4.33 against 4.33 ms per decode: by the stamps below a layer GEMM spends 2.6 of its 5.5 us
-//  waiting for X, the previous kernel's output, to cross from the other XCDs' L2 through memory; the weights are not what it waits for.)
+//  waiting for X, the previous kernel's output, to cross from the other XCDs' L2 through memory; the weights are not what it waits for.
+//  Also measured and removed: producer -> consumer pairs on ONE XCD where the data flow allows it (c_attn -> attention per head,
+//  c_fc -> mlp.c_proj per k-slice; ids dealt so that only XCDs 0-3 work): the consumers did not get faster at all (attention 5.21
+//  against 5.20 us -- what a kernel leaves in its XCD's L2 does not survive the kernel boundary as a hit for the next one) and the
+//  GEMMs that then stream through half the XCDs lose 1.3-1.5 us each: 5.1 against 4.5 ms per decode.)
 // out[n][j] = epilogue( sum_k X[n][k] * W[j][k] )        W [Nout][K] ([out][in]), X [N][K]
 //   grid = (ceil(Nout/16), KS) workgroups of NWV waves; each wave owns CPW*16 k's: K = KS * NWV * CPW * 16
 //   (KS = 1: K = 768 or 512; KS = 4: K = 3072).  NWV = 4; 8 at more than 32 prefixes, where the X loads (all of
