@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../.."
 name=$1; shift
 out=tools/microbench/bin/var_$name; mkdir -p $out
 for s in api.cpp vit_gemm.hip vit_gemm256.hip vit_gemm_roll.hip vit_attention.hip vit_fp32.hip vit_misc.hip region.hip project.hip decoder.hip viecap.hip preprocess.hip; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -w -I include -I patchioner_amd/csrc "$@" -c patchioner_amd/csrc/$s -o $out/${s%.*}.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -w -mllvm -amdgpu-kernarg-preload-count=16 -I include -I patchioner_amd/csrc "$@" -c patchioner_amd/csrc/$s -o $out/${s%.*}.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/microbench/bin/libpio_$name.so $out/*.o
