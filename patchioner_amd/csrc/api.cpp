@@ -906,6 +906,10 @@ static int run_vit_block(pio_handle c, const VitLayerDev& L, int B, const GemmAr
                          float* qkv_last, hipStream_t s) {
   const int D = c->D, M = B * c->Tp;
   const double Malg = (double)B * c->T;   // algorithmic rows: no pad tokens
+  // TIMING ablation (wrong results, diagnostic runs only): PIO_ABL_SKIP_LN=1 leaves the two LayerNorm launches of every block out --
+  // the upper bound of what ANY folding of LayerNorm into its neighbours could save (round 4, profiles/r04_bench_sweep.log)
+  static const bool skip_ln = getenv("PIO_ABL_SKIP_LN") != nullptr && getenv("PIO_ABL_SKIP_LN")[0] == '1';
+  if (!skip_ln)
   PROF(c, PIO_PROF_VIT_LN, 0, Malg * D * 6.0, s,
        launch_layernorm(c->op, c->x, L.n1w, L.n1b, c->cfg.vit_ln_eps, M, D, c->xn, nullptr, c->T, c->Tp, s));
   {
@@ -920,6 +924,7 @@ static int run_vit_block(pio_handle c, const VitLayerDev& L, int B, const GemmAr
     a.A = c->ao; a.lda = D; a.W = L.projw; a.bias = L.projb; a.ls = L.ls1; a.M = M; a.N = D; a.K = D;
     PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * D * D, 0, s, launch_vit_gemm(c->op, EPI_RESIDUAL, a, s));
   }
+  if (!skip_ln)
   PROF(c, PIO_PROF_VIT_LN, 0, Malg * D * 6.0, s,
        launch_layernorm(c->op, c->x, L.n2w, L.n2b, c->cfg.vit_ln_eps, M, D, c->xn, nullptr, c->T, c->Tp, s));
   {
