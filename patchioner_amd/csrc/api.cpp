@@ -906,9 +906,14 @@ static int run_vit_block(pio_handle c, const VitLayerDev& L, int B, const GemmAr
                          float* qkv_last, hipStream_t s) {
   const int D = c->D, M = B * c->Tp;
   const double Malg = (double)B * c->T;   // algorithmic rows: no pad tokens
-  // TIMING ablation (wrong results, diagnostic runs only): PIO_ABL_SKIP_LN=1 leaves the two LayerNorm launches of every block out --
-  // the upper bound of what ANY folding of LayerNorm into its neighbours could save (round 4, profiles/r04_bench_sweep.log)
+  // TIMING ablation, compiled only into diagnostic builds (-DPIO_ABLATIONS; tools/microbench/ln_ablation.sh): PIO_ABL_SKIP_LN=1 leaves
+  // the two LayerNorm launches of every block out (wrong results) -- the upper bound of what ANY folding of LayerNorm into its
+  // neighbours could save: +9.8 % captions/s through the pipeline, +3.9 % on a synchronous forward (profiles/r04_bench_sweep.log)
+#ifdef PIO_ABLATIONS
   static const bool skip_ln = getenv("PIO_ABL_SKIP_LN") != nullptr && getenv("PIO_ABL_SKIP_LN")[0] == '1';
+#else
+  constexpr bool skip_ln = false;
+#endif
   if (!skip_ln)
   PROF(c, PIO_PROF_VIT_LN, 0, Malg * D * 6.0, s,
        launch_layernorm(c->op, c->x, L.n1w, L.n1b, c->cfg.vit_ln_eps, M, D, c->xn, nullptr, c->T, c->Tp, s));

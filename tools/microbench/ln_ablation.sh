@@ -1,6 +1,8 @@
 #!/bin/bash
-# A/B: LayerNorm launches present / left out (timing ablation), default bench at 128 steps, two alternations
-mkdir -p gpurun_out/r4b
+# A/B: LayerNorm launches present / left out (TIMING ablation, wrong results), default bench at 128 steps, two alternations.
+# Needs the diagnostic build:  tools/microbench/build_variant.sh abl -DPIO_ABLATIONS
+mkdir -p gpurun_out
+export PIO_LIB_PATH=$PWD/tools/microbench/bin/libpio_abl.so
 for r in 1 2; do
 for v in with_ln skip_ln; do
   if [ $v = skip_ln ]; then export PIO_ABL_SKIP_LN=1; else unset PIO_ABL_SKIP_LN; fi
