@@ -903,7 +903,7 @@ static int run_vit_block_f32(pio_handle c, int l, int B, float* qkv_last, const 
 // One pre-LN DINOv2 block on the B sequences of c->x (in place): LN1 -> qkv -> attention -> proj (+LayerScale,
 // +residual) -> LN2 -> fc1 + GELU -> fc2 (+LayerScale, +residual).  `at.lens` (optional) = per-sequence token counts.
 static int run_vit_block(pio_handle c, const VitLayerDev& L, int B, const GemmArgs& g, const VitAttnArgs& at,
-                         float* qkv_last, hipStream_t s) {
+                         float* qkv_last, hipStream_t s, const VitLayerDev* next = nullptr) {
   const int D = c->D, M = B * c->Tp;
   const double Malg = (double)B * c->T;   // algorithmic rows: no pad tokens
   // TIMING ablation, compiled only into diagnostic builds (-DPIO_ABLATIONS; tools/microbench/ln_ablation.sh): PIO_ABL_SKIP_LN=1 leaves
@@ -921,12 +921,14 @@ static int run_vit_block(pio_handle c, const VitLayerDev& L, int B, const GemmAr
     GemmArgs a = g;
     a.A = c->xn; a.lda = D; a.W = L.qkvw; a.bias = L.qkvb; a.M = M; a.N = 3 * D; a.K = D;
     a.qkv_last = qkv_last;
+    a.pf = L.projw; a.pf_bytes = D * D * 2;          // each GEMM's spare workgroups warm the next one's weights (GemmArgs::pf)
     PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * 3.0 * D * D, 0, s, launch_vit_gemm(c->op, EPI_QKV, a, s));
   }
   PROF(c, PIO_PROF_VIT_ATTN, 4.0 * B * (double)c->T * c->T * D, 0, s, launch_vit_attention(c->op, at, s));
   {
     GemmArgs a = g;
     a.A = c->ao; a.lda = D; a.W = L.projw; a.bias = L.projb; a.ls = L.ls1; a.M = M; a.N = D; a.K = D;
+    a.pf = L.fc1w; a.pf_bytes = 4 * D * D * 2;
     PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * D * D, 0, s, launch_vit_gemm(c->op, EPI_RESIDUAL, a, s));
   }
   if (!skip_ln)
@@ -936,11 +938,13 @@ static int run_vit_block(pio_handle c, const VitLayerDev& L, int B, const GemmAr
     GemmArgs a = g;
     a.A = c->xn; a.lda = D; a.W = L.fc1w; a.bias = L.fc1b; a.out16 = c->hbuf; a.M = M; a.N = 4 * D; a.K = D;
     a.act = c->cfg.vit_arch == 1 ? 1 : 0;
+    a.pf = L.fc2w; a.pf_bytes = 4 * D * D * 2;
     PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * 4.0 * D * D, 0, s, launch_vit_gemm(c->op, EPI_GELU, a, s));
   }
   {
     GemmArgs a = g;
     a.A = c->hbuf; a.lda = 4 * D; a.W = L.fc2w; a.bias = L.fc2b; a.ls = L.ls2; a.M = M; a.N = D; a.K = 4 * D;
+    if (next != nullptr) { a.pf = next->qkvw; a.pf_bytes = 3 * D * D * 2; }
     PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * 4.0 * D * D, 0, s, launch_vit_gemm(c->op, EPI_RESIDUAL, a, s));
   }
   return PIO_OK;
@@ -990,7 +994,7 @@ int pio_vit_forward(pio_handle c, const float* imgs, int32_t B, float* tokens, f
   at.Tk = c->Tk; at.D = D; at.scale = 0.125f;  // 64^-0.5
   const int depth = c->cfg.depth;
   for (int l = 0; l < depth; ++l) {
-    const int rc = run_vit_block(c, c->vl[l], B, g, at, (l == depth - 1) ? qkv_last : nullptr, s);
+    const int rc = run_vit_block(c, c->vl[l], B, g, at, (l == depth - 1) ? qkv_last : nullptr, s, l + 1 < depth ? &c->vl[l + 1] : nullptr);
     if (rc != PIO_OK) return rc;
   }
   if (c->vhead_w) {

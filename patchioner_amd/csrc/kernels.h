@@ -18,6 +18,9 @@ enum GemmEpilogue {
   EPI_GELU = 3          // out16[m][n] = gelu_erf(acc + bias[n])                         (operand type)
 };
 
+#ifndef PIO_GEMM_WARM_NEXT      // extra workgroups that touch the next GEMM's weights (GemmArgs::pf); 0: never launched
+#define PIO_GEMM_WARM_NEXT 1
+#endif
 struct GemmArgs {
   const void* A;   // [M][lda] operand type, K contiguous
   const void* W;   // [N][K]   operand type, K contiguous (torch Linear layout)
@@ -32,7 +35,25 @@ struct GemmArgs {
   float* qkv_last;     // optional fp32 capture [B][T][3D]
   int T, Tp, Tk, G, n2, D, H;  // tokens / padded rows per image / padded key count / global tokens / patches
   int act;             // EPI_GELU: 0 = exact-erf GELU (DINOv2), 1 = QuickGELU x * sigmoid(1.702 x) (OpenAI-CLIP towers)
+  // optional: weights of the NEXT GEMM of the block, touched (one dword per 128-B line) by a few extra workgroups on compute units the
+  // tiles leave idle, so that they wait in the Infinity Cache instead of HBM (round 4, vit_gemm.hip: "cold weights")
+  const void* pf = nullptr;
+  int pf_bytes = 0;
 };
+// the extra workgroups' body: workgroup e of ne, nthr threads each
+__device__ __forceinline__ void gemm_warm_next(const GemmArgs& g, int e, int ne, int tid, int nthr) {
+  const int lines = g.pf_bytes >> 7;
+  const char* p = (const char*)g.pf;
+  unsigned acc = 0;
+  for (int l0 = e * nthr + tid; l0 < lines; l0 += 8 * ne * nthr) {       // eight loads in flight per lane
+    unsigned r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const int l = l0 + i * ne * nthr; r[i] = l < lines ? *(const unsigned*)(p + (size_t)l * 128) : 0u; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc |= r[i];
+  }
+  asm volatile("" :: "v"(acc));
+}
 
 hipError_t launch_vit_gemm(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
 // 256 x 256 tiles, 8 waves (vit_gemm256.hip): same arithmetic per output element; launch_vit_gemm dispatches to it

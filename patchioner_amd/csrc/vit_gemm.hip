@@ -71,7 +71,12 @@ __global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? PIO_GEMM_WIDE_OCC
   const int wm = wid >> 1, wn = wid & 1, h = lane >> 5, r31 = lane & 31;
 
   const int ntn = g.N / BN;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntiles = ((g.M + BM - 1) / BM) * ntn;
+  if ((int)blockIdx.x >= ntiles) {            // extra workgroups (launch_one): warm the Infinity Cache with the next GEMM's weights
+    gemm_warm_next(g, blockIdx.x - ntiles, gridDim.x - ntiles, tid, 256);
+    return;
+  }
+  const int bid = xcd_remap(blockIdx.x, ntiles);
   const int tn = bid % ntn, tm = bid / ntn;
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? PIO_GEMM_WIDE_OCC
 #define PIO_GEMM_BIG_M 8192
 #endif
 #ifndef PIO_GEMM_NBUF_NARROW
-#define PIO_GEMM_NBUF_NARROW 2
+#define PIO_GEMM_NBUF_NARROW 3
 #endif
 
 template <typename T, int EPI, int BM, int NBUF>
@@ -327,7 +332,10 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int grid = ceil_div(a.M, BM) * (a.N / BN);
+  // "cold weights" (round 4): in a synchronous forward the bank pass of the projection has swept the Infinity Cache, so every weight
+  // matrix comes from HBM once per forward; behind a 768-MB sweep fc2 at 16 images takes 48.4 instead of 37.0 us
+  // (tools/microbench/gemm256_bench.hip cold).  32 extra workgroups read the next GEMM's weights while this one computes.
+  const int grid = ceil_div(a.M, BM) * (a.N / BN) + (PIO_GEMM_WARM_NEXT && a.pf != nullptr && a.pf_bytes > 0 ? 32 : 0);
   hipLaunchKernelGGL((k_vit_gemm<T, EPI, BM, NBUF>), dim3(grid), dim3(256), smem_bytes, s, a);
   return hipGetLastError();
 }

@@ -93,7 +93,12 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm256(const GemmArgs g) {
 
   G256_STAMP(0);
   const int ntn = g.N / TN;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntiles = ((g.M + TM - 1) / TM) * ntn;
+  if ((int)blockIdx.x >= ntiles) {            // extra workgroups on idle compute units: the next GEMM's weights (vit_gemm.hip, "cold weights")
+    gemm_warm_next(g, blockIdx.x - ntiles, gridDim.x - ntiles, tid, 512);
+    return;
+  }
+  const int bid = xcd_remap(blockIdx.x, ntiles);
   const int tn = bid % ntn, tm = bid / ntn;
   const int m0 = tm * TM, n0 = tn * TN;
 
@@ -426,7 +431,10 @@ static hipError_t launch256_one(const GemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int grid = ceil_div(a.M, g256::TM) * (a.N / g256::TN);
+  // one workgroup owns a compute unit: extra (weight-warming) workgroups only where the tiles leave compute units idle
+  const int tiles = ceil_div(a.M, g256::TM) * (a.N / g256::TN);
+  const int spare = tiles < 256 ? (256 - tiles < 16 ? 256 - tiles : 16) : 0;
+  const int grid = tiles + (PIO_GEMM_WARM_NEXT && a.pf != nullptr && a.pf_bytes > 0 ? spare : 0);
   hipLaunchKernelGGL((k_vit_gemm256<T, EPI>), dim3(grid), dim3(512), g256::LDS_BYTES, s, a);
   return hipGetLastError();
 }

@@ -113,6 +113,15 @@ int main(int argc, char** argv) {
     }
   }
   printf("qkv  (LN, store)   %7.2f us   old %7.2f us\n", time_chain([&] { dec_gemm<DE_STORE, 1>(w_qkv, x, N, 3 * E, E, bias, qkv, nullptr, cvec, 1e-5f, nullptr, nullptr, s); }), time_chain([&] { dec_gemm_rg<12, 1, DE_STORE, 1>(w_qkv, x, N, 3 * E, E, bias, qkv, nullptr, cvec, 1e-5f, nullptr, nullptr, s); }));
+  {  // round 4: what a fused c_attn + (attn.c_proj folded into V) GEMM would cost: 768 + 768 + 4 x 768 = 4608 output columns
+    float *w2, *o2; CK(hipMalloc(&w2, (size_t)6 * E * E * 4)); CK(hipMalloc(&o2, (size_t)N * 6 * E * 4));
+    CK(hipMemcpy(w2, h.data(), (size_t)6 * E * E * 4, hipMemcpyHostToDevice));
+    printf("qkv' 4608 cols     %7.2f us\n", time_chain([&] { dec_gemm<DE_STORE, 1>(w2, x, N, 6 * E, E, bias, o2, nullptr, cvec, 1e-5f, nullptr, nullptr, s); }));
+    // ... and in a chain with another kernel between (so that its X is not L2-hot from the previous launch of itself)
+    printf("qkv' + proj chain  %7.2f us per pair   qkv + proj chain %7.2f us per pair\n",
+           time_chain([&] { dec_gemm<DE_STORE, 1>(w2, x, N, 6 * E, E, bias, o2, nullptr, cvec, 1e-5f, nullptr, nullptr, s); dec_gemm<DE_RESID, 0>(w_proj, att, N, E, E, bias, x, nullptr, nullptr, 0.f, ws, cnt, s); }),
+           time_chain([&] { dec_gemm<DE_STORE, 1>(w_qkv, x, N, 3 * E, E, bias, qkv, nullptr, cvec, 1e-5f, nullptr, nullptr, s); dec_gemm<DE_RESID, 0>(w_proj, att, N, E, E, bias, x, nullptr, nullptr, 0.f, ws, cnt, s); }));
+  }
   printf("attention pos=15   %7.2f us\n", time_chain([&] { hipLaunchKernelGGL(k_dec_attention, dim3(N * heads), dim3(256), 0, s, qkv, kc, vc, E, heads, 15, S, att); }));
   printf("attention pos=29   %7.2f us\n", time_chain([&] { hipLaunchKernelGGL(k_dec_attention, dim3(N * heads), dim3(256), 0, s, qkv, kc, vc, E, heads, 29, S, att); }));
   printf("proj (resid)       %7.2f us\n", time_chain([&] { dec_gemm<DE_RESID, 0>(w_proj, att, N, E, E, bias, x, nullptr, nullptr, 0.f, ws, cnt, s); }));

@@ -176,6 +176,43 @@ static void time_all(int B, int side, int D) {
   release(b);
 }
 
+// round 4: the library's own dispatch (launch_vit_gemm) timed ONE launch at a time behind a cache sweep: 64 MB evicts the 8 x 4 MB of
+// L2 (operands then come from the Infinity Cache), 768 MB the Infinity Cache as well (operands from HBM) -- in a synchronous
+// forward the GEMMs run 35 % slower than back to back here (fc2 at 16 images: 44.7 against 33.2 us), and this says which state that is
+__global__ __launch_bounds__(256) void k_sweep(const float4* __restrict__ p, size_t n4, float* sink) {
+  float a = 0.f;
+  for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) { const float4 v = p[i]; a += v.x + v.y + v.z + v.w; }
+  if (a == 123.456f) *sink = a;
+}
+static void time_cold(int B, int side, int D) {
+  Bufs b = make(B, side, D, false);
+  CK(hipMemset(b.ls, 0, D * 4));
+  float* sw; float* sink; const size_t big = (size_t)768 << 20;
+  CK(hipMalloc(&sw, big)); CK(hipMalloc(&sink, 64)); CK(hipMemset(sw, 0, big));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  printf("B=%d (M=%d): one launch at a time, median us: back to back | behind a 64-MB sweep (L2 cold) | behind a 768-MB sweep (Infinity Cache cold)\n", B, b.M);
+  for (const Case& c : CASES) {
+    GemmArgs g = args_for(b, c);
+    printf("  %s %6dx%4dx%4d ", c.name, g.M, g.N, g.K);
+    for (size_t bytes : {(size_t)0, (size_t)64 << 20, big}) {
+      std::vector<float> tt;
+      for (int r = 0; r < 15; ++r) {
+        if (bytes) hipLaunchKernelGGL(k_sweep, dim3(2048), dim3(256), 0, 0, (const float4*)sw, bytes / 16, sink);
+        CK(hipEventRecord(e0, 0));
+        CK(launch_vit_gemm(OP_F16, c.e, g, 0));
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        tt.push_back(ms * 1e3f);
+      }
+      std::sort(tt.begin(), tt.end());
+      printf(" | %7.1f", tt[tt.size() / 2]);
+    }
+    printf("\n");
+  }
+  CK(hipFree(sw)); CK(hipFree(sink));
+  release(b);
+}
+
 // where a tile's cycles go: s_memtime stamps of every workgroup (entry, first operands landed, main loop done, end)
 static void stamps(int B, int side, int D) {
   Bufs b = make(B, side, D, false);
@@ -266,6 +303,10 @@ int main(int argc, char** argv) {
     printf("check (518^2, 37 x 37 patches)\n");
     bad += check(8, 37, 768, false);
     printf(bad ? "CHECK FAILED\n" : "CHECK OK\n");
+  }
+  if (mode == "cold") {
+    unsetenv("PIO_GEMM256_MIN_TILES"); unsetenv("PIO_GEMM_ROLL_MIN_TILES");     // the library's own dispatch thresholds
+    for (int B : Bs) time_cold(B, 16, 768);
   }
   if (mode == "stamps")
     for (int B : Bs) stamps(B, 16, 768);
