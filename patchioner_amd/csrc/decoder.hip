@@ -155,7 +155,12 @@ __device__ __forceinline__ float gelu_new(float x) {
 //  Also measured and removed: producer -> consumer pairs on ONE XCD where the data flow allows it (c_attn -> attention per head,
 //  c_fc -> mlp.c_proj per k-slice; ids dealt so that only XCDs 0-3 work): the consumers did not get faster at all (attention 5.21
 //  against 5.20 us -- what a kernel leaves in its XCD's L2 does not survive the kernel boundary as a hit for the next one) and the
-//  GEMMs that then stream through half the XCDs lose 1.3-1.5 us each: 5.1 against 4.5 ms per decode.)
+//  GEMMs that then stream through half the XCDs lose 1.3-1.5 us each: 5.1 against 4.5 ms per decode.
+//  And, built and removed in the same round: attn.c_proj folded into the value projection (v'_h = W_p[:, h] W_v[h], one fused matrix
+//  per head built at load in fp64; the attention then finishes the residual branch itself and a layer is four kernels instead of
+//  five).  Ids identical to the oracle on every decoder test -- and 4.68 against 4.18 ms per decode: the (2 + H) E = 4 608-column
+//  c_attn takes 7.9 instead of 5.5 us in the chain and the attention that reads H x the value bytes (8 workgroups per prefix, each
+//  needing all four heads' keys) 11.0 instead of 5.2: more than the 5.4 us of the launch it removes.)
 // out[n][j] = epilogue( sum_k X[n][k] * W[j][k] )        W [Nout][K] ([out][in]), X [N][K]
 //   grid = (ceil(Nout/16), KS) workgroups of NWV waves; each wave owns CPW*16 k's: K = KS * NWV * CPW * 16
 //   (KS = 1: K = 768 or 512; KS = 4: K = 3072).  NWV = 4; 8 at more than 32 prefixes, where the X loads (all of
