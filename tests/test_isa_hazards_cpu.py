@@ -1,0 +1,72 @@
+"""Static check of the BUILT gfx950 code for a hazard hipcc cannot see inside inline asm (round 4).
+
+A VALU instruction that reads the result of a transcendental instruction (v_exp / v_log / v_rcp / v_rsq / v_sqrt / v_sin / v_cos)
+needs one wait state between them on gfx940-class parts.  hipcc's hazard recogniser inserts it for the instructions IT emits, not for
+instructions that arrive as inline-asm text: vit_attention.hip's soft-max (an asm v_add_f32 behind the compiler's v_exp_f32) produced
+run-to-run differences the moment the scheduler put such a pair back to back.  So: disassemble every kernel of the shipped library and
+require that no instruction reads a register that the instruction directly before it wrote with a transcendental opcode.  Runs on the
+CPU (llvm-objdump); nothing is executed."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "patchioner_amd", "libpatchioner_hip.so")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+TRANS = re.compile(r"^v_(exp|log|rcp|rcp_iflag|rsq|sqrt|sin|cos)_(f32|f16|legacy_f32)")
+
+
+def _regs(tok):
+    """vN or v[a:b] -> set of VGPR numbers (the token may carry modifiers: -v3, |v3|, v3.l ...)"""
+    out = set()
+    for m in re.finditer(r"v\[(\d+):(\d+)\]|(?<![a-z_\d])v(\d+)", tok):
+        if m.group(1) is not None:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def scan(path, tmp_path):
+    """-> (violations, kernels seen, transcendental instructions seen) of the gfx950 code objects bundled in ``path``"""
+    lib = os.path.join(tmp_path, "lib.so")
+    shutil.copy(path, lib)
+    subprocess.run([OBJDUMP, "--offloading", lib], check=True, capture_output=True, cwd=tmp_path)
+    objs = [os.path.join(tmp_path, f) for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert objs, "no gfx950 code object in the library"
+    bad, kernels, trans = [], 0, 0
+    for o in objs:
+        dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", o], check=True, capture_output=True, text=True).stdout
+        func, prev = None, None
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                func, prev = m.group(1), None
+                kernels += 1
+                continue
+            ins = line.strip().split("//")[0].strip()
+            if not ins or ins.endswith(":"):
+                continue
+            parts = ins.split(None, 1)
+            op, args = parts[0], (parts[1] if len(parts) > 1 else "")
+            toks = [t.strip() for t in args.split(",")]
+            if prev is not None:
+                dst, pop = prev
+                srcs = toks[1:] if op.startswith("v_") and not op.startswith("v_cmp") else toks   # VOPC writes vcc / an SGPR: every token is a source
+                if op.startswith(("v_", "ds_", "global_", "buffer_", "flat_", "scratch_")) and any(_regs(t) & dst for t in srcs):
+                    bad.append("%s: %s -> %s" % (func, pop, ins))
+            prev = None
+            if TRANS.match(op) and toks:
+                trans += 1
+                prev = (_regs(toks[0]), ins)
+    return bad, kernels, trans
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="needs the built library and llvm-objdump")
+def test_no_transcendental_result_is_read_by_the_next_instruction(tmp_path):
+    bad, kernels, trans = scan(LIB, tmp_path)
+    assert kernels > 20 and trans > 100, (kernels, trans)          # the scan saw the library's kernels and their transcendentals
+    assert not bad, "a transcendental's result is read one instruction later (missing wait state):\n" + "\n".join(bad[:20])
