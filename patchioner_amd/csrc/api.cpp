@@ -822,8 +822,8 @@ static int bank_common(pio_context* c, int64_t rows, int32_t dim) {
       HIP_OK(launch_split_bank(c->bank, rows, dim, c->bank_scale, c->bank_split, nullptr));
     }
   }
-  if ((rc = c->dmalloc(&c->part_acc, (size_t)c->parts * 16 * dim))) return rc;
-  if ((rc = c->dmalloc(&c->part_ml, (size_t)c->parts * 16 * 2))) return rc;
+  if ((rc = c->dmalloc(&c->part_acc, (size_t)c->parts * 24 * dim))) return rc;      // 24: 48 queries x parts / 2 workgroups (project.hip)
+  if ((rc = c->dmalloc(&c->part_ml, (size_t)c->parts * 24 * 2))) return rc;
   if ((rc = c->dmalloc(&c->sims, (size_t)16 * rows))) return rc;
   HIP_OK(hipDeviceSynchronize());
   return PIO_OK;
@@ -1115,10 +1115,10 @@ int pio_mem_project(pio_handle c, float* q, int32_t N, float temperature, int32_
   ProjectArgs a;
   a.bank = c->bank; a.inv_norm = c->bank_inv; a.M = c->bank_rows; a.D = c->bank_dim; a.q = q; a.N = N;
   a.temperature = temperature; a.normalize = normalize; a.out = out; a.n_best = n_best; a.best_sims = best_sims;
-  a.part_acc = c->part_acc; a.part_ml = c->part_ml; a.part_best = c->sims; a.parts = c->parts; a.n_best_cap = 16;
+  a.part_acc = c->part_acc; a.part_ml = c->part_ml; a.part_best = c->sims; a.parts = c->parts; a.n_best_cap = 16; a.part_rows = c->parts * 24;
   a.bank_scale = c->bank_scale; a.bank_split = c->bank_split;
-  double passes = 0;                         // bank passes as launch_mem_project makes them: 32 queries while more than 16 are left
-  for (int left = N; left > 0; left -= left > 16 ? 32 : 16) passes += 1;
+  double passes = 0;                         // bank passes as launch_mem_project makes them: 48 queries while more than 32 are left (D = 768), 32 while more than 16
+  for (int left = N; left > 0; left -= (left > 32 && !(left > 48 && left <= 64) && c->bank_dim == 768) ? 48 : (left > 16 ? 32 : 16)) passes += 1;
   PROF(c, PIO_PROF_MEM_PROJECT, 4.0 * N * (double)c->bank_rows * c->bank_dim,
        passes * ((double)c->bank_rows * c->bank_dim * 4.0 + (double)c->bank_rows * 4.0), (hipStream_t)stream,
        launch_mem_project(a, (hipStream_t)stream));

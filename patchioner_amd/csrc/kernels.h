@@ -132,6 +132,7 @@ struct ProjectArgs {
   float* part_ml;         // [parts][N][2]  (running max, running sum)
   float* part_best;       // [parts][N][n_best_cap]
   int parts; int n_best_cap;
+  int part_rows = 0;      // rows of part_acc / part_ml the context allocated (16 parts; 24 parts allows the 48-query pass)
   float bank_scale;       // > 0 with bank_split: both GEMMs on split fp16 operands (bank * bank_scale = hi + lo; a power of two with
   const void* bank_split; // max|bank| * scale <= 2^15; [M][2][D] fp16, launch_split_bank); 0 / null: the exact fp32 form
 };

@@ -26,6 +26,9 @@ namespace pio {
 #ifndef PIO_PROJECT_Q32       // 32 queries per bank pass when more than 16 are left
 #define PIO_PROJECT_Q32 1
 #endif
+#ifndef PIO_PROJECT_Q48       // 48 queries per bank pass when more than 32 are left (D = 768)
+#define PIO_PROJECT_Q48 1
+#endif
 #ifndef PIO_PROJECT_RT32      // 16-row tiles per loop iteration of the 32-query form
 #define PIO_PROJECT_RT32 2
 #endif
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(256) void k_revert(const float* __restrict__ x, con
 
 template <int D, int NQG, bool SPLIT>
 static hipError_t project_pass(const ProjectArgs& a, int q0, int parts, hipStream_t s) {
-  constexpr int RT = NQG == 2 ? PIO_PROJECT_RT32 : 1;           // slab boundaries in units of 16 RT rows (as in rounds 1 and 2)
+  constexpr int RT = NQG >= 2 ? PIO_PROJECT_RT32 : 1;           // slab boundaries in units of 16 RT rows (as in rounds 1 and 2)
   const int smem = (2 * PR_ROWS * (D + (SPLIT ? 8 : 4)) + NQG * 4 * 256) * (int)sizeof(float);
   static bool attr_set[64] = {};                                  // function attributes are per device
   int dev = 0;
@@ -617,12 +620,17 @@ static hipError_t project_pass(const ProjectArgs& a, int q0, int parts, hipStrea
 
 template <int NQG>
 static hipError_t project_pass_d(const ProjectArgs& a, int q0, int parts, hipStream_t s) {
-  const bool split = a.bank_scale > 0.f && a.bank_split != nullptr && (NQG == 2 || PIO_PROJECT_SPLIT16);
-  switch (a.D) {
-    case 384: return split ? project_pass<384, NQG, true>(a, q0, parts, s) : project_pass<384, NQG, false>(a, q0, parts, s);
-    case 512: return split ? project_pass<512, NQG, true>(a, q0, parts, s) : project_pass<512, NQG, false>(a, q0, parts, s);
-    case 768: return split ? project_pass<768, NQG, true>(a, q0, parts, s) : project_pass<768, NQG, false>(a, q0, parts, s);
-    default: return hipErrorInvalidValue;
+  const bool split = a.bank_scale > 0.f && a.bank_split != nullptr && (NQG >= 2 || PIO_PROJECT_SPLIT16);
+  if constexpr (NQG == 3) {      // 48 queries per pass: the tile's 48 LDS-DMA operations divide among 12 waves only at D = 768
+    if (a.D != 768) return hipErrorInvalidValue;
+    return split ? project_pass<768, 3, true>(a, q0, parts, s) : project_pass<768, 3, false>(a, q0, parts, s);
+  } else {
+    switch (a.D) {
+      case 384: return split ? project_pass<384, NQG, true>(a, q0, parts, s) : project_pass<384, NQG, false>(a, q0, parts, s);
+      case 512: return split ? project_pass<512, NQG, true>(a, q0, parts, s) : project_pass<512, NQG, false>(a, q0, parts, s);
+      case 768: return split ? project_pass<768, NQG, true>(a, q0, parts, s) : project_pass<768, NQG, false>(a, q0, parts, s);
+      default: return hipErrorInvalidValue;
+    }
   }
 }
 
@@ -632,14 +640,20 @@ hipError_t launch_mem_project(const ProjectArgs& a, hipStream_t s) {
   for (int q0 = 0; q0 < a.N;) {
     // more than 16 queries left: one pass of 32 (512-thread workgroups, one per CU: parts / 2 of them, same partial
     // buffers with 32 queries per workgroup); else a pass of 16
+    // round 4: more than 32 left (and D = 768, the split image): one pass of 48 -- 768-thread workgroups, three query groups on
+    // one tile stream (12 waves x 164 VGPRs fill a CU); the pass is bandwidth-bound, so queries 33..48 ride almost free
+    // (80 queries of a 5-batch ViT launch: 48 + 32 instead of 32 + 32 + 16)
     const int left = a.N - q0;
-    const bool wide = PIO_PROJECT_Q32 && left > PR_Q;
-    const int nq = wide ? (left < 2 * PR_Q ? left : 2 * PR_Q) : (left < PR_Q ? left : PR_Q);
-    const int parts = wide ? a.parts / 2 : a.parts;
-    const hipError_t e = wide ? project_pass_d<2>(a, q0, parts, s) : project_pass_d<1>(a, q0, parts, s);
+    // (49 .. 64 left: 32 + 32 beats 48 + 16 -- 0.82 against 0.87 ms; tools/microbench/project_time.py)
+    const bool q48 = PIO_PROJECT_Q48 && left > 2 * PR_Q && !(left > 3 * PR_Q && left <= 4 * PR_Q) && a.D == 768 &&
+                     a.part_rows >= 3 * PR_Q * (a.parts / 2);
+    const int groups = q48 ? 3 : (PIO_PROJECT_Q32 && left > PR_Q ? 2 : 1);
+    const int cap = groups * PR_Q, nq = left < cap ? left : cap;
+    const int parts = groups >= 2 ? a.parts / 2 : a.parts;
+    const hipError_t e = groups == 3 ? project_pass_d<3>(a, q0, parts, s) : (groups == 2 ? project_pass_d<2>(a, q0, parts, s) : project_pass_d<1>(a, q0, parts, s));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_project_combine, dim3(nq, a.D / 64), dim3(256), 0, s, a.part_acc, a.part_ml, parts, a.D,
-                       q0, wide ? 2 * PR_Q : PR_Q, a.out);
+                       q0, cap, a.out);
     q0 += nq;
   }
   if (a.normalize) hipLaunchKernelGGL(k_l2norm_rows, dim3(a.N), dim3(256), 0, s, a.out, a.D);

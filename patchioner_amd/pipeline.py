@@ -103,7 +103,9 @@ class TraceCaptionPipeline:
         # batches whose embeddings share one projection call: one 32-query bank pass serves two batches (0.44 instead
         # of 0.56 ms per batch for the projection alone).  Holding a batch back just for that gained nothing (5.24 k vs
         # 5.27 k captions/s); batches that already share a ViT launch are projected in pairs (+2 %: 6.02 k vs 5.90 k).
-        self.project_batches = min(2, self.vit_batches)
+        # Round 4: the projection has a 48-query pass (768-thread workgroups: 0.53 ms against 0.44 for 32 and 0.37 for 16), so ALL the
+        # batches of a ViT launch are projected in one call: 80 queries = 48 + 32 (0.92 ms) instead of 32 + 32 + 16 (1.25 ms).
+        self.project_batches = max(1, int(os.environ.get("PIO_PROJECT_BATCHES", "0")) or self.vit_batches)
         self.use_attention_tracing = use_attention_tracing
         self.steps = steps
         # Stage 1 may be confined to the first `stage_cus` compute units so that the decode's small dependent
