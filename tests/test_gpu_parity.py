@@ -282,7 +282,7 @@ def test_projection_ragged_shapes_vs_oracle(O, D, M, form):
             bank[5] = 0
         e.set_memory_bank(bank)
         kept = bank[bank.norm(dim=-1) != 0]
-        for N in (1, 16, 17, 32, 47, 128):
+        for N in (1, 16, 17, 32, 33, 47, 64, 80, 128):      # 16- / 32- / 48-query passes and their mixes (project.hip: launch_mem_project)
             q = torch.randn(N, D, generator=g)
             got = e.project(dev(q), normalize=True)
             again = e.project(dev(q), normalize=True)
