@@ -339,6 +339,24 @@ def main():
         torch.cuda.synchronize()
         prof_pipe = model.engine.profile_read()
         model.engine.profile_enable(False)
+    # ... and the SAME launches (VB batches per ViT launch) with nothing else in flight: an event pair on the launch stream also brackets
+    # the time a launch waits for compute units that other streams' kernels hold, so inside the pipeline it reads ~13-17 % above the
+    # kernel's own duration (rocprofv3's begin -> end, profiles/r0N_vit_gemm_pipelined_by_grid.csv).  `roofline` is taken HERE -- the
+    # kernel's launch duration, which is what the committed rocprofv3 summary has to agree with -- and the in-pipeline figure stays in the
+    # line as `roofline_in_pipeline`.
+    prof_alone = None
+    if pipe is not None and VB > 1:
+        big = torch.cat([imgs] * VB)
+        for _ in range(2):
+            model.engine.vit_forward(big, want_qkv=True)
+        torch.cuda.synchronize()
+        model.engine.profile_enable(True)
+        for _ in range(6):
+            model.engine.vit_forward(big, want_qkv=True)
+        torch.cuda.synchronize()
+        prof_alone = model.engine.profile_read()
+        model.engine.profile_enable(False)
+        del big
     assert len(outs["trace_capts"]) == BATCH and ids.shape[0] == BATCH * world
     # Image transforms (the reference times them apart from inference, eval_trace_captioning.py:233-262): 16 camera-sized
     # RGB images -> [16,3,224,224] on the device (pio_preprocess: raw pixels over PCIe, resize / crop / normalise on the
@@ -398,8 +416,13 @@ def main():
                     "flops_per_launch": g["flops"] / max(g["launches"], 1)}
         roof_sync = roofline_of(prof["vit_gemm"], BATCH, "one synchronous forward at a time", tj.get("vit_gemm_hbm_bytes_per_launch"))
         roof = roof_sync
+        roof_pipe = None
         if prof_pipe is not None and prof_pipe["vit_gemm"]["launches"] > 0:
-            roof = roofline_of(prof_pipe["vit_gemm"], BATCH * VB, "inside the pipelined timed region's launch pattern",
+            roof_pipe = roofline_of(prof_pipe["vit_gemm"], BATCH * VB, "inside the pipelined timed region, decodes of other streams in flight: "
+                                    "the brackets include the wait for compute units", tj.get("vit_gemm_hbm_bytes_per_launch_pipelined"))
+            roof = roof_pipe
+        if prof_alone is not None and prof_alone["vit_gemm"]["launches"] > 0:
+            roof = roofline_of(prof_alone["vit_gemm"], BATCH * VB, "the pipelined region's launch size, nothing else in flight: the kernel's own launch duration",
                                tj.get("vit_gemm_hbm_bytes_per_launch_pipelined"))
         stages = {}
         for k, v in prof.items():
@@ -436,6 +459,7 @@ def main():
                        "pipelining": "none" if P == 1 else ("one decode per %d batches (up to %d decodes in flight, one decoder clone and stream each), overlapped with the next batches' ViT (one launch per %d batches) on %d stream(s)" % (P, DS, VB, S)
                                                            if args.mode == "group" else "%d forwards on %d streams" % (P, P))},
             "roofline": roof,
+            "roofline_in_pipeline": roof_pipe,
             "roofline_sync": roof_sync,
             "sync": {"value": BATCH * world * sync_steps / dt_sync, "unit": "captions/s", "steps": sync_steps,
                      "ms_per_step": dt_sync / sync_steps * 1e3,
