@@ -5,7 +5,13 @@ needs one wait state between them on gfx940-class parts.  hipcc's hazard recogni
 instructions that arrive as inline-asm text: vit_attention.hip's soft-max (an asm v_add_f32 behind the compiler's v_exp_f32) produced
 run-to-run differences the moment the scheduler put such a pair back to back.  So: disassemble every kernel of the shipped library and
 require that no instruction reads a register that the instruction directly before it wrote with a transcendental opcode.  Runs on the
-CPU (llvm-objdump); nothing is executed."""
+CPU (llvm-objdump); nothing is executed.
+
+The same holds for MFMA results: a VALU / memory instruction that reads (or overwrites) a matrix instruction's destination needs
+passes + 2 wait states behind a plain fp32 MFMA and passes + 4 behind an XDL one on gfx950 (LLVM's GCNHazardRecogniser:
+checkMAIVALUHazards), and the recogniser does not look inside inline asm either -- the soft-max and epilogue asm statements of
+vit_attention.hip / vit_gemm*.hip consume accumulators.  Second check below: no such instruction inside the window (straight-line
+code only: the scan forgets what is pending at an unconditional branch)."""
 import os
 import re
 import shutil
@@ -28,6 +34,72 @@ def _regs(tok):
         else:
             out.add(int(m.group(3)))
     return out
+
+
+def _regs_va(tok):
+    """like _regs for both register files: {('v', n), ('a', n)}"""
+    out = set()
+    for m in re.finditer(r"([va])\[(\d+):(\d+)\]|(?<![a-z_\d])([va])(\d+)", tok):
+        if m.group(1) is not None:
+            out.update((m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1))
+        else:
+            out.add((m.group(4), int(m.group(5))))
+    return out
+
+
+def _mfma_window(op):
+    """wait states an MFMA's destination must not be touched for (gfx950; passes of 4 cycles)"""
+    if "32x32x16" in op or "16x16x16" in op:
+        return 8 + 4          # XDL, 8 passes
+    if "16x16x32" in op:
+        return 4 + 4          # XDL, 4 passes
+    if "16x16x4_f32" in op or "16x16x4f32" in op:
+        return 8 + 2          # fp32: not XDL
+    if "32x32x2" in op:
+        return 16 + 2
+    if "4x4" in op:
+        return 2 + 4
+    return 16 + 4             # anything else: the longest
+
+
+def scan_mfma(path, tmp_path):
+    """-> (violations, MFMA instructions seen)"""
+    lib = os.path.join(tmp_path, "lib.so")
+    shutil.copy(path, lib)
+    subprocess.run([OBJDUMP, "--offloading", lib], check=True, capture_output=True, cwd=tmp_path)
+    objs = [os.path.join(tmp_path, f) for f in os.listdir(tmp_path) if "gfx950" in f]
+    bad, seen = [], 0
+    for o in objs:
+        dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", o], check=True, capture_output=True, text=True).stdout
+        func, pend = None, []                                      # pend: (destination registers, wait states still needed, text)
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                func, pend = m.group(1), []
+                continue
+            ins = line.strip().split("//")[0].strip()
+            if not ins or ins.endswith(":"):
+                continue
+            parts = ins.split(None, 1)
+            op, args = parts[0], (parts[1] if len(parts) > 1 else "")
+            toks = [t.strip() for t in args.split(",")]
+            if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                pend = []
+                continue
+            mfma = op.startswith(("v_mfma", "v_smfmac"))
+            if not mfma and op.startswith(("v_", "ds_", "global_", "buffer_", "flat_", "scratch_")):
+                touched = set()
+                for t in toks:                                     # sources and destination alike: RAW and WAW
+                    touched |= _regs_va(t)
+                for dst, left, text in pend:
+                    if touched & dst:
+                        bad.append("%s: %s -> (%d wait states short) %s" % (func, text, left, ins))
+            step = int(toks[0], 0) + 1 if op == "s_nop" else 1
+            pend = [(d, left - step, t) for d, left, t in pend if left - step > 0]
+            if mfma:
+                seen += 1
+                pend.append((_regs_va(toks[0]), _mfma_window(op), ins))
+    return bad, seen
 
 
 def scan(path, tmp_path):
@@ -70,3 +142,10 @@ def test_no_transcendental_result_is_read_by_the_next_instruction(tmp_path):
     bad, kernels, trans = scan(LIB, tmp_path)
     assert kernels > 20 and trans > 100, (kernels, trans)          # the scan saw the library's kernels and their transcendentals
     assert not bad, "a transcendental's result is read one instruction later (missing wait state):\n" + "\n".join(bad[:20])
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="needs the built library and llvm-objdump")
+def test_no_mfma_destination_is_touched_inside_its_hazard_window(tmp_path):
+    bad, seen = scan_mfma(LIB, tmp_path)
+    assert seen > 5000, seen
+    assert not bad, "an MFMA's destination is read or overwritten before its wait states have passed:\n" + "\n".join(bad[:20])
