@@ -80,6 +80,9 @@ namespace pio {
 #ifndef PIO_LMHEAD_CG
 #define PIO_LMHEAD_CG 1
 #endif
+#ifndef PIO_DEC_DENSE          // diagnostic: fewer, larger workgroups for the layer GEMMs above 64 prefixes (1: 64 rows x 64 columns, 2: 64 x 32)
+#define PIO_DEC_DENSE 0
+#endif
 #ifndef PIO_DEC_LEAN_TICKET   // split-K slabs through agent-scope relaxed atomics (sc1 accesses) instead of release / acquire fences (round 4)
 #define PIO_DEC_LEAN_TICKET 1
 #endif
@@ -855,6 +858,13 @@ static hipError_t dec_gemm(const float* W, const float* X, int N, int Nout, int 
     const int rg = ceil_div(N, 16);
     if (rg >= 2 && K == 768 && Nout % 48 == 0) {
       const bool wide = Nout >= 2304;       // qkv / fc: 48 (32) columns per workgroup; proj: 16
+#if PIO_DEC_DENSE == 1
+      if (rg > 4) return wide ? dec_gemm_b_launch<4, 4, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s)
+                              : dec_gemm_b_launch<4, 1, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
+#elif PIO_DEC_DENSE == 2
+      if (rg > 4) return wide ? dec_gemm_b_launch<4, 2, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s)
+                              : dec_gemm_b_launch<4, 1, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
+#endif
       if (rg > 4) return wide ? dec_gemm_b_launch<2, 3, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s)
                               : dec_gemm_b_launch<2, 1, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
       if (rg > 2) return wide ? dec_gemm_b_launch<2, 2, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s)
