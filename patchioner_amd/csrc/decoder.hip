@@ -32,7 +32,7 @@ namespace pio {
 #ifndef PIO_DABL_NOX
 #define PIO_DABL_NOX 0
 #endif
-#ifndef PIO_DABL_NOMFMA      // 1: only the first sixth of every layer GEMM's fp32 MFMAs is issued (what a split-fp16 form would cost the matrix pipe: 3 / 16)
+#ifndef PIO_DABL_NOMFMA      // 2: every fp32 MFMA of this file on a 2-pass instruction (a quarter of the pipe time, same dataflow); 1: only the first sixth of every layer GEMM's fp32 MFMAs is issued (what a split-fp16 form would cost the matrix pipe: 3 / 16)
 #define PIO_DABL_NOMFMA 0
 #endif
 // minimum waves per SIMD requested for k_dec_gemm.  (5 => <= 96 VGPRs would let decode waves sit beside two
@@ -102,7 +102,11 @@ __device__ unsigned long long g_dec_stamps[8][512][8];     // [kind = EPI + 4 (K
 #endif
 
 __device__ __forceinline__ f32x4 mfma16f(float a, float b, f32x4 c) {
+#if PIO_DABL_NOMFMA == 2   // timing ablation: the same operands and dependences on a 2-pass instruction (8 instead of 32 cycles of the matrix pipe); wrong results
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+#else
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
 }
 
 // torch.argmax order: NaN counts as the maximum, ties (and several NaNs) go to the lowest index.  A prefix of NaNs
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? PIO_DEC_GEMM_WAVES : 1) void k
 #pragma unroll
     for (int cc = 0; cc < CPW; cc += 2) {
       const float4 x0 = PIO_XC(cc), x1 = PIO_XC(cc + 1);
-      if (PIO_DABL_NOMFMA && cc >= CPW / 6) { a0[0] += x0.x * w4[cc].x + x0.w * w4[cc].w; a1[0] += x1.x * w4[cc + 1].x + x1.w * w4[cc + 1].w; continue; }
+      if (PIO_DABL_NOMFMA == 1 && cc >= CPW / 6) { a0[0] += x0.x * w4[cc].x + x0.w * w4[cc].w; a1[0] += x1.x * w4[cc + 1].x + x1.w * w4[cc + 1].w; continue; }
       a0 = mfma16f(x0.x, w4[cc].x, a0);  a1 = mfma16f(x1.x, w4[cc + 1].x, a1);
       a0 = mfma16f(x0.y, w4[cc].y, a0);  a1 = mfma16f(x1.y, w4[cc + 1].y, a1);
       a0 = mfma16f(x0.z, w4[cc].z, a0);  a1 = mfma16f(x1.z, w4[cc + 1].z, a1);
@@ -721,7 +725,7 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_b(const float* __rest
     const float* _xb = lsm + ((q) % RB) * XB;                                                                  \
     _Pragma("unroll") for (int g = 0; g < RGB; ++g) {                                                          \
       const float4 xf = *(const float4*)(_xb + (16 * g + li) * CH + (((4 * kw + kq) ^ li) << 2));              \
-      if (PIO_DABL_NOMFMA && (q) >= 2) { acc[g][0] += xf.x * w[q][0] + xf.w * w[q][3]; continue; }             \
+      if (PIO_DABL_NOMFMA == 1 && (q) >= 2) { acc[g][0] += xf.x * w[q][0] + xf.w * w[q][3]; continue; }             \
       acc[g] = mfma16f(xf.x, w[q][0], acc[g]);                                                                 \
       acc[g] = mfma16f(xf.y, w[q][1], acc[g]);                                                                 \
       acc[g] = mfma16f(xf.z, w[q][2], acc[g]);                                                                 \
