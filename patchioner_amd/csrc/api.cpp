@@ -457,6 +457,26 @@ int finalize_decoder(pio_context* c) {
     if ((rc = upload_f32(c, tb->data.data(), E, &dw))) return rc;
     w.fc2_b = dw;
   }
+  // split-fp16 copies of the three wide layer matrices for decodes of more than 64 prefixes (decoder.hip: k_dec_gemm_s; same bytes as
+  // the fp32 ones; PIO_DEC_SPLIT=0 keeps the fp32 kernels everywhere)
+  {
+    const char* ev = getenv("PIO_DEC_SPLIT");
+    if (E == 768 && !(ev && ev[0] == '0')) {
+      for (int l = 0; l < L; ++l) {
+        DecLayerW& w = c->dl[l];
+        struct { const float* src; size_t n; const void** dst; float* un; } m[3] = {
+            {w.attn_w, (size_t)3 * E * E, &w.attn_ws, &w.attn_un}, {w.fc_w, (size_t)4 * E * E, &w.fc_ws, &w.fc_un},
+            {w.fc2_w, (size_t)4 * E * E, &w.fc2_ws, &w.fc2_un}};
+        for (auto& e : m) {
+          void* d = nullptr;
+          if ((rc = c->dmalloc_bytes(&d, e.n * 4))) return rc;
+          float un = 0.f;
+          if (dec_split_weights(e.src, e.n, d, &un, nullptr) != hipSuccess) continue;    // non-finite weights: the fp32 kernels serve this matrix
+          *e.dst = d; *e.un = un;
+        }
+      }
+    }
+  }
   HIP_OK(decoder_init());
   if ((rc = alloc_decoder_workspaces(c))) return rc;
   c->has_dec = true;

@@ -25,6 +25,8 @@
 //     next input embedding.
 #include "common.h"
 #include "kernels.h"
+#include <cmath>
+#include <cstring>
 
 namespace pio {
 
@@ -101,6 +103,11 @@ __device__ unsigned long long g_dec_stamps[8][512][8];     // [kind = EPI + 4 (K
 #define PIO_STAMP(i) do {} while (0)
 #endif
 
+typedef _Float16 dec_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 dec_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 dec_h4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ f32x4 mfma16f(float a, float b, f32x4 c) {
 #if PIO_DABL_NOMFMA == 2   // timing ablation: the same operands and dependences on a 2-pass instruction (8 instead of 32 cycles of the matrix pipe); wrong results
   return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
@@ -130,6 +137,16 @@ __device__ __forceinline__ float row16_max(float v) {
   v = fmaxf(v, dpp_f32<0x141>(v));    // row_half_mirror: lane i <-> 7 - i
   v = fmaxf(v, dpp_f32<0x140>(v));    // row_mirror:      lane i <-> 15 - i
   return v;
+}
+
+// sum over the wave without the LDS crossbar: four DPP steps inside each row of 16 lanes, then the rows through v_permlane16/32_swap
+// (a __shfl_xor butterfly is six dependent ds_bpermute round trips, ~130 cycles each)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_f32<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);     // row_half_mirror
+  v += dpp_f32<0x140>(v);     // row_mirror
+  return xor32_add(xor16_add(v));
 }
 
 // A split-K partial tile crosses XCDs (each has its own L2).  Round 1 published it with an agent-scope RELEASE fence (an L2 write-back)
@@ -845,11 +862,244 @@ static hipError_t dec_gemm_b_launch(const float* W, const float* X, int N, int N
   return hipGetLastError();
 }
 
+// ---- layer GEMMs above 16 prefixes on split-fp16 operands (PIO_DEC_SPLIT) ------------------------------------------------
+// The fp32 MFMA (v_mfma_f32_16x16x4_f32: 256 flop / clk / CU) is what a k_dec_gemm_b workgroup spends its residency on at 64+
+// prefixes (tools/microbench: a quarter of the pipe time = -15 % of a 128-prefix decode).  Here both operands are pairs of fp16
+// numbers, x S = hi + lo' 2^-11 with hi = fp16(x S) and lo' = fp16((x S - hi) 2^11) -- 22 bits of the 24, the low half kept in the
+// normal range by its 2^11 -- and a product is three v_mfma_f32_16x16x32_f16 (hi hi into one accumulator; hi lo' + lo' hi into a
+// second one, added with 2^-11 at the end; the lo' lo' term, 2^-22 of the product, is dropped): 48 instead of 256 pipe cycles per
+// 32 k.  The weights are split ONCE at load into the same bytes ([column][8-k group][hi x 8 | lo' x 8] fp16: one 32-B read per lane
+// and k-step); the activations are split by the workgroup that multiplies them, while it stages its 32 rows into LDS (two fp16
+// planes, rows padded to 1552 B: the 16 rows of a fragment read fall on 16 distinct 16-B slots) -- which is also where the
+// LayerNorm row sums are taken now, once per element instead of once per column-group wave.
+//   grid = (Nout / (16 NCG), KS, ceil(N / 32)), 256 NCG threads: wave (cg, kw) owns 16 columns and the k-steps kw, kw + 4, .. of
+//   the workgroup's 768-k slice; the four k-quarter partials meet in LDS in order, then the epilogues of k_dec_gemm_b.
+static constexpr float DEC_SPLIT_XS = 0.0625f;          // activations are scaled by 2^-4 before the split (|x| < 2^20 stays finite in fp16)
+__global__ __launch_bounds__(256) void k_dec_split_weights(const float* __restrict__ W, size_t n8, float S, u32x4_t* __restrict__ out) {
+  for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < n8; g += (size_t)gridDim.x * 256) {
+    const float4 a = *(const float4*)(W + g * 8), b = *(const float4*)(W + g * 8 + 4);
+    const float v[8] = {a.x * S, a.y * S, a.z * S, a.w * S, b.x * S, b.y * S, b.z * S, b.w * S};
+    dec_h8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      hi[i] = (_Float16)v[i];
+      lo[i] = (_Float16)((v[i] - (float)hi[i]) * 2048.0f);
+    }
+    out[2 * g] = __builtin_bit_cast(u32x4_t, hi);
+    out[2 * g + 1] = __builtin_bit_cast(u32x4_t, lo);
+  }
+}
+__global__ __launch_bounds__(256) void k_dec_abs_max(const float* __restrict__ x, size_t n, uint32_t* out) {
+  uint32_t m = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const uint32_t b = __float_as_uint(x[i]) & 0x7FFFFFFFu;      // non-negative floats order like their bits
+    m = b > m ? b : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(m, o); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+hipError_t launch_dec_split_weights(const float* W, size_t n, float S, void* out, hipStream_t s);
+hipError_t dec_split_weights(const float* W, size_t n, void* out, float* unscale, hipStream_t s) {
+  uint32_t* d = nullptr;
+  hipError_t e = hipMalloc((void**)&d, 4);
+  if (e != hipSuccess) return e;
+  uint32_t bits = 0;
+  e = hipMemsetAsync(d, 0, 4, s);
+  if (e == hipSuccess) { hipLaunchKernelGGL(k_dec_abs_max, dim3(512), dim3(256), 0, s, W, n, d); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemcpyAsync(&bits, d, 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(d);
+  if (e != hipSuccess) return e;
+  float amax;
+  memcpy(&amax, &bits, 4);
+  if (!(amax < 3.0e38f)) return hipErrorInvalidValue;           // NaN / inf weights: keep the fp32 kernels
+  int sh = 0;
+  if (amax > 0.f) sh = 13 - ilogbf(amax);                       // |W| * 2^sh < 2^14
+  const float S = ldexpf(1.0f, sh);
+  *unscale = 1.0f / (S * DEC_SPLIT_XS);
+  e = launch_dec_split_weights(W, n, S, out, s);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(s);
+}
+hipError_t launch_dec_split_weights(const float* W, size_t n, float S, void* out, hipStream_t s) {
+  if (n % 8 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_dec_split_weights, dim3(1024), dim3(256), 0, s, W, n / 8, S, (u32x4_t*)out);
+  return hipGetLastError();
+}
+
+template <int NCG, int KS, int EPI, int LN>
+__global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __restrict__ Ws, const float* __restrict__ X, int N, int Nout, int K,
+                                                             const float* __restrict__ bias, float* out, const float* __restrict__ cvec,
+                                                             float eps, float unscale, float* ws, unsigned* cnt) {
+  static_assert(!(LN && KS > 1), "LayerNorm row sums need the whole row in one workgroup");
+  constexpr int NW = 4 * NCG, ROWS = 32, RGB = 2, PSTR = 768 * 2 + 16, PLANE = ROWS * PSTR, NIT = 96 / NW;
+  static_assert(NIT * NW == 96, "a row is three 64-lane chunks: 96 chunks must divide among the waves");
+  extern __shared__ __attribute__((aligned(16))) char lss[];       // hi plane, lo plane; afterwards partial tiles [NW][RGB][256] fp32
+  __shared__ float s_sum[LN ? ROWS : 1][3], s_sq[LN ? ROWS : 1][3];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int cg = wid >> 2, kw = wid & 3;
+  const int row0 = blockIdx.z * ROWS;
+  const int kbase = blockIdx.y * 768;
+  const int j = (blockIdx.x * NCG + cg) * 16 + li;
+  // the weight stream: k-step s = kw + 4 i covers the 8-k groups 4 s .. 4 s + 3, this lane takes group 4 s + kq: 32 B
+  const u32x4_t* wp = Ws + ((size_t)j * (K >> 3) + (kbase >> 3) + 4 * kw + kq) * 2;
+  u32x4_t wh[6], wl[6];
+  // the activations: chunk c = wid + NW it is part c % 3 (64 float4) of row c / 3; split, planes, row sums
+  constexpr int XB = NIT % 8 == 0 ? 8 : 6;            // float4 in flight per thread and batch (NIT = 8, 12 or 24)
+  static_assert(NIT % XB == 0, "whole batches");
+#pragma unroll
+  for (int b0 = 0; b0 < NIT; b0 += XB) {
+    float4 xs[XB];
+#pragma unroll
+    for (int i = 0; i < XB; ++i) {
+      const int c = wid + NW * (b0 + i), row = c / 3, part = c - 3 * row;
+      const int rc = row0 + row < N ? row0 + row : N - 1;
+      xs[i] = *(const float4*)(X + (size_t)rc * K + kbase + 4 * (64 * part + lane));
+    }
+    if (b0 == 0) {          // loads return in order: the first batch of activations (what the split waits for), then the weight stream
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        wh[i] = wp[32 * i];
+        wl[i] = wp[32 * i + 1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < XB; ++i) {
+      const int c = wid + NW * (b0 + i), row = c / 3, part = c - 3 * row;
+      const float4 x = xs[i];
+      const float v0 = x.x * DEC_SPLIT_XS, v1 = x.y * DEC_SPLIT_XS, v2 = x.z * DEC_SPLIT_XS, v3 = x.w * DEC_SPLIT_XS;
+      const dec_h2 h01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v0, v1)), h23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v2, v3));
+      const dec_h2 l01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v0 - (float)h01[0]) * 2048.0f, (v1 - (float)h01[1]) * 2048.0f));
+      const dec_h2 l23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v2 - (float)h23[0]) * 2048.0f, (v3 - (float)h23[1]) * 2048.0f));
+      char* const d = lss + row * PSTR + 8 * (64 * part + lane);
+      *(dec_h4*)d = (dec_h4){h01[0], h01[1], h23[0], h23[1]};
+      *(dec_h4*)(d + PLANE) = (dec_h4){l01[0], l01[1], l23[0], l23[1]};
+      if (LN) {
+        const float sx = wave_sum_dpp((x.x + x.y) + (x.z + x.w));
+        const float sq = wave_sum_dpp((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w));
+        if (lane == 0) { s_sum[row][part] = sx; s_sq[row][part] = sq; }
+      }
+    }
+  }
+  __syncthreads();
+  f32x4 a0[RGB], a1[RGB];
+#pragma unroll
+  for (int g = 0; g < RGB; ++g) { a0[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; a1[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int sgrp = 4 * (kw + 4 * i) + kq;            // this lane's 8-k group of the slice
+    const dec_h8 bh = __builtin_bit_cast(dec_h8, wh[i]), bl = __builtin_bit_cast(dec_h8, wl[i]);
+#pragma unroll
+    for (int g = 0; g < RGB; ++g) {
+      const char* rp = lss + (16 * g + li) * PSTR + 16 * sgrp;
+      const dec_h8 xh = *(const dec_h8*)rp, xl = *(const dec_h8*)(rp + PLANE);
+      a0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bh, a0[g], 0, 0, 0);
+      a1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bl, a1[g], 0, 0, 0);
+      a1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, bh, a1[g], 0, 0, 0);
+    }
+  }
+  const float bj = bias[j];
+  const float cj = LN ? cvec[j] : 0.f;
+  __syncthreads();                                  // every wave is done with the planes: reuse them for the partial tiles
+  float* const lsm = (float*)lss;
+#pragma unroll
+  for (int g = 0; g < RGB; ++g) *(f32x4*)(lsm + ((wid * RGB + g) * 64 + lane) * 4) = (a0[g] + a1[g] * (1.0f / 2048.0f)) * unscale;
+  __syncthreads();
+  const int g = kw;
+  const bool fin = kw < RGB;                        // wave-uniform: wave (cg, kw < 2) finishes row group kw of its column group
+  f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (fin) {
+    s = *(const f32x4*)(lsm + (((cg * 4 + 0) * RGB + g) * 64 + lane) * 4);
+#pragma unroll
+    for (int k2 = 1; k2 < 4; ++k2) s += *(const f32x4*)(lsm + (((cg * 4 + k2) * RGB + g) * 64 + lane) * 4);
+  }
+  if constexpr (KS > 1) {
+    constexpr int NP = NCG * RGB;
+    const int tile = blockIdx.z * gridDim.x + blockIdx.x;
+    float* tbase = ws + (size_t)tile * KS * NP * 256;
+    const int pr = cg * RGB + g;
+    if (fin) st_agent(tbase + ((size_t)blockIdx.y * NP + pr) * 256 + lane * 4, s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned t = __hip_atomic_fetch_add(cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == (unsigned)(KS - 1));
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) __hip_atomic_store(cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    if (fin) {
+      const float* sp = tbase + (size_t)pr * 256 + lane * 4;
+      s = ld_agent(sp);
+#pragma unroll
+      for (int y = 1; y < KS; ++y) s += ld_agent(sp + (size_t)y * NP * 256);
+    }
+  }
+  if (!fin) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = g * 16 + 4 * kq + i, n = row0 + rr;
+    if (n >= N) continue;
+    float v;
+    if (LN) {
+      const float tx = (s_sum[rr][0] + s_sum[rr][1]) + s_sum[rr][2];
+      const float tq = (s_sq[rr][0] + s_sq[rr][1]) + s_sq[rr][2];
+      const float mu = tx / (float)K;
+      const float var = fmaxf(tq / (float)K - mu * mu, 0.f);
+      v = rsqrtf(var + eps) * (s[i] - mu * cj) + bj;
+    } else {
+      v = s[i] + bj;
+    }
+    float* o = out + (size_t)n * Nout + j;
+    if constexpr (EPI == DE_STORE) *o = v;
+    else if constexpr (EPI == DE_RESID) *o += v;
+    else if constexpr (EPI == DE_GELU) *o = gelu_new(v);
+  }
+}
+
+template <int NCG, int KS, int EPI, int LN>
+static hipError_t dec_gemm_s_launch(const void* Ws, float unscale, const float* X, int N, int Nout, int K, const float* bias, float* out,
+                                    const float* cvec, float eps, float* ws, unsigned* cnt, hipStream_t s) {
+  const dim3 grid(Nout / (16 * NCG), KS, ceil_div(N, 32));
+  if (K != KS * 768 || Nout % (16 * NCG) != 0 || N < 1 || N > DEC_MAX_PREFIXES || Ws == nullptr) return hipErrorInvalidValue;
+  if (KS > 1 && ((int)(grid.x * grid.z) > DEC_MAX_COLGROUPS || (size_t)grid.x * grid.z * KS * NCG * 2 * 256 > DEC_SPLITK_WS_FLOATS || !ws || !cnt))
+    return hipErrorInvalidValue;
+  constexpr int smem = 2 * 32 * (768 * 2 + 16);
+  static DeviceOnce attr_once; bool& attr_set = attr_once.flag();
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_dec_gemm_s<NCG, KS, EPI, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_dec_gemm_s<NCG, KS, EPI, LN>), grid, dim3(256 * NCG), smem, s, (const u32x4_t*)Ws, X, N, Nout, K, bias, out, cvec, eps,
+                     unscale, ws, cnt);
+  return hipGetLastError();
+}
+
 // K = 768 (4 waves x 12 chunks), 512 (4 x 8) or 3072 (4 workgroups x 4 waves x 12, split-K with `ws` / `cnt`)
+#ifndef PIO_DEC_SPLIT_MIN_RG    // 16-row groups from which the layer GEMMs take the split-fp16 form when the split weights exist (5: 65+ prefixes)
+#define PIO_DEC_SPLIT_MIN_RG 5
+#endif
 template <int EPI, int LN>
 static hipError_t dec_gemm(const float* W, const float* X, int N, int Nout, int K, const float* bias, float* out,
-                           const float* extra, const float* cvec, float eps, float* ws, unsigned* cnt, hipStream_t s) {
+                           const float* extra, const float* cvec, float eps, float* ws, unsigned* cnt, hipStream_t s,
+                           const void* Wsplit = nullptr, float unscale = 0.f) {
   if (N < 1 || N > DEC_MAX_PREFIXES) return hipErrorInvalidValue;
+  if constexpr (EPI == DE_STORE || EPI == DE_RESID || EPI == DE_GELU) {
+    if (Wsplit != nullptr && ceil_div(N, 16) >= PIO_DEC_SPLIT_MIN_RG && Nout % 48 == 0) {
+      if (K == 768) return dec_gemm_s_launch<3, 1, EPI, LN>(Wsplit, unscale, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
+      if constexpr (EPI == DE_RESID && !LN) {
+        if (K == 3072 && Nout <= 768 && ws != nullptr && cnt != nullptr)
+          return dec_gemm_s_launch<3, 4, EPI, LN>(Wsplit, unscale, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
+      }
+    }
+  }
   if constexpr (EPI == DE_EMBED) {
     // the prefix projection runs once per decode on k_dec_gemm (<= 128 rows per launch): 129 .. 256 prefixes as two launches
     if (N > 128) {
@@ -1082,7 +1332,6 @@ static hipError_t launch_lmhead_wide(const float* W, const float* X, int N, int 
 // If v* is the exact arg-max then logit~[v*] >= logit[v*] - B >= logit[v~] - B >= logit~[v~] - 2B for the approximate
 // arg-max v~: v* (and every exact tie) passes the filter.  A further slack of 1e-5 (1 + |max|) absorbs the fp32
 // rounding of the affine step.  NaN rows decode to id 0 like torch.argmax.
-typedef _Float16 dec_h8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void k_lm_prep(const float* __restrict__ x, int K, float eps, float bound_coef,
                                                  _Float16* __restrict__ xh, float* __restrict__ stats) {
@@ -1517,11 +1766,11 @@ static hipError_t dec_layers_step(const DecoderArgs& a, int pos, hipStream_t s) 
     const DecLayerW& w = a.layer[l];
     float* kc = a.kcache + (size_t)l * N * a.max_steps * E;
     float* vc = a.vcache + (size_t)l * N * a.max_steps * E;
-    PIO_TRY((dec_gemm<DE_STORE, 1>(w.attn_w, a.x, N, 3 * E, E, w.attn_d, a.qkv, nullptr, w.attn_c, a.eps, nullptr, nullptr, s)));
+    PIO_TRY((dec_gemm<DE_STORE, 1>(w.attn_w, a.x, N, 3 * E, E, w.attn_d, a.qkv, nullptr, w.attn_c, a.eps, nullptr, nullptr, s, w.attn_ws, w.attn_un)));
     hipLaunchKernelGGL(k_dec_attention, dim3(N * a.heads), dim3(256), 0, s, a.qkv, kc, vc, E, a.heads, pos, a.max_steps, a.att);
     PIO_TRY((dec_gemm<DE_RESID, 0>(w.proj_w, a.att, N, E, E, w.proj_b, a.x, nullptr, nullptr, 0.f, nullptr, nullptr, s)));
-    PIO_TRY((dec_gemm<DE_GELU, 1>(w.fc_w, a.x, N, 4 * E, E, w.fc_d, a.hid, nullptr, w.fc_c, a.eps, nullptr, nullptr, s)));
-    PIO_TRY((dec_gemm<DE_RESID, 0>(w.fc2_w, a.hid, N, E, 4 * E, w.fc2_b, a.x, nullptr, nullptr, 0.f, a.splitk_ws, a.splitk_cnt, s)));
+    PIO_TRY((dec_gemm<DE_GELU, 1>(w.fc_w, a.x, N, 4 * E, E, w.fc_d, a.hid, nullptr, w.fc_c, a.eps, nullptr, nullptr, s, w.fc_ws, w.fc_un)));
+    PIO_TRY((dec_gemm<DE_RESID, 0>(w.fc2_w, a.hid, N, E, 4 * E, w.fc2_b, a.x, nullptr, nullptr, 0.f, a.splitk_ws, a.splitk_cnt, s, w.fc2_ws, w.fc2_un)));
   }
   return hipSuccess;
 }

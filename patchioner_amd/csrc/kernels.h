@@ -156,7 +156,14 @@ hipError_t launch_revert(const float* x, const float* b, const float* A_pinv, in
 struct DecLayerW {
   const float *attn_w /*[3E][E] folded*/, *attn_c, *attn_d, *proj_w /*[E][E]*/, *proj_b;
   const float *fc_w /*[4E][E] folded*/, *fc_c, *fc_d, *fc2_w /*[E][4E]*/, *fc2_b;
+  // the same matrices as split-fp16 operands (decoder.hip, k_dec_gemm_s; null: fp32 kernels only) and 1 / (their power-of-two scale x the
+  // activations' scale)
+  const void *attn_ws = nullptr, *fc_ws = nullptr, *fc2_ws = nullptr;
+  float attn_un = 0.f, fc_un = 0.f, fc2_un = 0.f;
 };
+// W [n] fp32 -> split-fp16 layout ([row][8-k group][hi x 8 | lo' x 8]), same bytes; *unscale = 1 / (S x activation scale), S = the power of
+// two that puts max |W| into [2^13, 2^14).  Synchronises (load time only).
+hipError_t dec_split_weights(const float* W, size_t n, void* out, float* unscale, hipStream_t s);
 static constexpr int DEC_MAX_PREFIXES = 256;       // rows of one greedy decode (ids only; log-probabilities: 64 per call)
 static constexpr int DEC_SPLITK_COUNTERS = 128;    // arrival tickets / slab groups of the in-launch split-K (api.cpp allocates them)
 struct DecoderArgs {
