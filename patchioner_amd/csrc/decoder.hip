@@ -948,46 +948,74 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
   // the weight stream: k-step s = kw + 4 i covers the 8-k groups 4 s .. 4 s + 3, this lane takes group 4 s + kq: 32 B
   const u32x4_t* wp = Ws + ((size_t)j * (K >> 3) + (kbase >> 3) + 4 * kw + kq) * 2;
   u32x4_t wh[6], wl[6];
-  // the activations: chunk c = wid + NW it is part c % 3 (64 float4) of row c / 3; split, planes, row sums
+  // the activations: chunk c = wid + NW it is part c % 3 (64 float4) of row c / 3; split, planes, row sums.
+  // Range: x xscale must stay below fp16's 65504 (v_cvt_pkrtz SATURATES, it does not overflow to inf).  The fixed 2^-4 covers |x| < 2^19;
+  // every wave reports the largest magnitude it staged, and a workgroup that saw more -- never in the decoders' own activations,
+  // but a caller may hand in any finite prefix and the fp32 kernels take it -- stages its slice again with a power-of-two scale
+  // chosen from that maximum (exact; undone in the epilogue).
   constexpr int XB = NIT % 8 == 0 ? 8 : 6;            // float4 in flight per thread and batch (NIT = 8, 12 or 24)
   static_assert(NIT % XB == 0, "whole batches");
+  __shared__ __attribute__((aligned(16))) float s_am[16];
+  auto stage = [&](const float xscale, const bool first) {
+    float am = 0.f;
 #pragma unroll
-  for (int b0 = 0; b0 < NIT; b0 += XB) {
-    float4 xs[XB];
+    for (int b0 = 0; b0 < NIT; b0 += XB) {
+      float4 xs[XB];
 #pragma unroll
-    for (int i = 0; i < XB; ++i) {
-      const int c = wid + NW * (b0 + i), row = c / 3, part = c - 3 * row;
-      const int rc = row0 + row < N ? row0 + row : N - 1;
-      xs[i] = *(const float4*)(X + (size_t)rc * K + kbase + 4 * (64 * part + lane));
-    }
-    if (b0 == 0) {          // loads return in order: the first batch of activations (what the split waits for), then the weight stream
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        wh[i] = wp[32 * i];
-        wl[i] = wp[32 * i + 1];
+      for (int i = 0; i < XB; ++i) {
+        const int c = wid + NW * (b0 + i), row = c / 3, part = c - 3 * row;
+        const int rc = row0 + row < N ? row0 + row : N - 1;
+        xs[i] = *(const float4*)(X + (size_t)rc * K + kbase + 4 * (64 * part + lane));
       }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+      if (first && b0 == 0) {   // loads return in order: the first batch of activations (what the split waits for), then the weight stream
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < XB; ++i) {
-      const int c = wid + NW * (b0 + i), row = c / 3, part = c - 3 * row;
-      const float4 x = xs[i];
-      const float v0 = x.x * DEC_SPLIT_XS, v1 = x.y * DEC_SPLIT_XS, v2 = x.z * DEC_SPLIT_XS, v3 = x.w * DEC_SPLIT_XS;
-      const dec_h2 h01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v0, v1)), h23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v2, v3));
-      const dec_h2 l01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v0 - (float)h01[0]) * 2048.0f, (v1 - (float)h01[1]) * 2048.0f));
-      const dec_h2 l23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v2 - (float)h23[0]) * 2048.0f, (v3 - (float)h23[1]) * 2048.0f));
-      char* const d = lss + row * PSTR + 8 * (64 * part + lane);
-      *(dec_h4*)d = (dec_h4){h01[0], h01[1], h23[0], h23[1]};
-      *(dec_h4*)(d + PLANE) = (dec_h4){l01[0], l01[1], l23[0], l23[1]};
-      if (LN) {
-        const float sx = wave_sum_dpp((x.x + x.y) + (x.z + x.w));
-        const float sq = wave_sum_dpp((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w));
-        if (lane == 0) { s_sum[row][part] = sx; s_sq[row][part] = sq; }
+        for (int i = 0; i < 6; ++i) {
+          wh[i] = wp[32 * i];
+          wl[i] = wp[32 * i + 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < XB; ++i) {
+        const int c = wid + NW * (b0 + i), row = c / 3, part = c - 3 * row;
+        const float4 x = xs[i];
+        const float v0 = x.x * xscale, v1 = x.y * xscale, v2 = x.z * xscale, v3 = x.w * xscale;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));
+        const dec_h2 h01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v0, v1)), h23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v2, v3));
+        const dec_h2 l01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v0 - (float)h01[0]) * 2048.0f, (v1 - (float)h01[1]) * 2048.0f));
+        const dec_h2 l23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v2 - (float)h23[0]) * 2048.0f, (v3 - (float)h23[1]) * 2048.0f));
+        char* const d = lss + row * PSTR + 8 * (64 * part + lane);
+        *(dec_h4*)d = (dec_h4){h01[0], h01[1], h23[0], h23[1]};
+        *(dec_h4*)(d + PLANE) = (dec_h4){l01[0], l01[1], l23[0], l23[1]};
+        if (LN && first) {
+          const float sx = wave_sum_dpp((x.x + x.y) + (x.z + x.w));
+          const float sq = wave_sum_dpp((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w));
+          if (lane == 0) { s_sum[row][part] = sx; s_sq[row][part] = sq; }
+        }
       }
     }
-  }
+    if (first) {
+      am = row16_max(am);
+      am = xor32_max(xor16_max(am));
+      if (lane == 0) s_am[wid] = am;
+    }
+  };
+  stage(DEC_SPLIT_XS, true);
   __syncthreads();
+  float amax = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; w += 4) {
+    const float4 m4 = *(const float4*)(s_am + w);
+    amax = fmaxf(fmaxf(amax, fmaxf(m4.x, m4.y)), fmaxf(m4.z, m4.w));
+  }
+  if (!(amax < 32768.f)) {                              // workgroup-uniform; inf lands here too (and stays inf / NaN, as in the fp32 kernels)
+    int e = amax < 3.0e38f ? ilogbf(amax) - 13 : 0;
+    e = e < 0 ? 0 : (e > 100 ? 100 : e);
+    stage(DEC_SPLIT_XS * ldexpf(1.0f, -e), false);
+    unscale *= ldexpf(1.0f, e);
+    __syncthreads();
+  }
   f32x4 a0[RGB], a1[RGB];
 #pragma unroll
   for (int g = 0; g < RGB; ++g) { a0[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; a1[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; }

@@ -363,6 +363,29 @@ def test_decoder_128_prefixes_in_one_call(golden):
         e.close()
 
 
+def test_decoder_split_fp16_layer_gemms_take_any_finite_prefix(golden):
+    """Above 64 prefixes the layer GEMMs run on split-fp16 operands (decoder.hip: k_dec_gemm_s): activations are scaled by a fixed
+    2^-4 before the split, and a workgroup that sees magnitudes beyond fp16's range stages its slice again with a scale chosen from
+    the maximum.  Rows scaled by 1e-6 ... 1e8 (the fp32 kernels take any finite prefix) decode to the ids the SAME rows give in
+    calls of 16, which run the fp32 kernels; 96 rows = three 32-row blocks, each holding small and huge rows side by side."""
+    from patchioner_amd.engine import Engine
+    e = Engine(embed_dim=768, depth=1, num_heads=12, num_registers=4, crop_dim=224, max_batch=2, max_prefixes=128, vit_dtype="fp16")
+    try:
+        e.load_state_dict(W.synth_dinov2(gc.E2E["seed_vit"], depth=1))
+        e.load_state_dict(W.synth_decap(gc.DEC["seed_w"]))
+        e.finalize()
+        x = gc.decoder_prefixes("raw")
+        big = x.repeat(-(-96 // x.shape[0]), 1)[:96].clone()
+        scales = torch.tensor([1.0, 1e4, 1e-6, 1e8, 3e5, 1.0, 7e6, 1e-3])[torch.arange(96) % 8]
+        big *= scales[:, None]
+        want = torch.cat([e.decode_greedy(big[i:i + 16])[0].cpu() for i in range(0, 96, 16)])
+        got, _ = e.decode_greedy(big)
+        assert np.array_equal(got.cpu().numpy(), want.numpy())
+        assert np.array_equal(want[0].numpy(), golden("decoder")["raw_ids"][0])       # the unscaled rows are the golden ones
+    finally:
+        e.close()
+
+
 def test_decoder_nan_prefix_decodes_like_torch_argmax(golden, eng224):
     """A prefix of NaNs (the reference's mean over an empty box region, bbox_utils.py:40-42 / 393) makes every logit NaN;
     torch.argmax then returns index 0.  The GPU arg-max orders NaN like torch (and never indexes wte out of range);

@@ -206,6 +206,10 @@ int main(int argc, char** argv) {
       TS("fc2", 2, 4, DE_RESID, 0, s_fc2, hid, E, 4 * E, x, nullptr);
       TS("fc2", 1, 4, DE_RESID, 0, s_fc2, hid, E, 4 * E, x, nullptr);
       TS("fc2", 3, 4, DE_RESID, 0, s_fc2, hid, E, 4 * E, x, nullptr);
+      TS("qkv", 4, 1, DE_STORE, 1, s_qkv, x, 3 * E, E, qkv, cvec);
+      TS("fc", 4, 1, DE_GELU, 1, s_fc, x, 4 * E, E, hid, cvec);
+      TS("fc2", 4, 4, DE_RESID, 0, s_fc2, hid, E, 4 * E, x, nullptr);
+      TS("proj", 3, 1, DE_RESID, 0, s_proj, att, E, E, x, nullptr);
     }
     CK(hipMemcpy(x, h.data(), (size_t)N * E * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(hid, h.data(), (size_t)N * 4 * E * 4, hipMemcpyHostToDevice));
   }
