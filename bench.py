@@ -27,6 +27,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # +1.2 % captions/s through the pipeline on one box, two alternations (8.58 against 8.47 k), nothing on the synchronous forward.
 # The same default as patchioner_amd/__init__.py and tests/conftest.py; the effective value is reported in `config.env`.
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# Eight hardware queues instead of HIP's four: the pipeline runs five streams side by side (caller, stage 1, three decodes), and whether two of them
+# shared a queue depended on creation order and on a timing probe (patchioner_amd/__init__.py); same throughput when nothing is aliased.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 
@@ -450,11 +453,11 @@ def main():
                                    "talk2dino_decap_COCO, ViT-B/14-reg 224^2, batch 16/GPU, caption_from=patches "
                                    "(one 16-patch trace region per image), bank 591753x768 fp32, 30-step greedy decode; `value` is measured "
                                    "through the throughput API (value_api), the drop-in forward() figure is forward_sync",
-                       "env": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
+                       "env": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
                        "arithmetic": {"vit": "fp16 operands, fp32 accumulation (v_mfma_f32_32x32x16_f16), fp32 residual stream / LayerNorm",
                                       "projection": "operands as fp16 hi + lo pairs (22 significant bits) on v_mfma_f32_16x16x32_f16, fp32 "
                                                     "accumulation and soft-max; as close to fp64 as an fp32 evaluation (DESIGN.md section 3)",
-                                      "decoder": "fp32 (v_mfma_f32_16x16x4_f32); greedy ids through an fp16 filter + exact fp32 re-evaluation"},
+                                      "decoder": "fp32 (v_mfma_f32_16x16x4_f32) at <= 64 prefixes per decode; above, the three wide layer GEMMs on fp16 hi + lo pairs (three v_mfma_f32_16x16x32_f16 per product, fp32 accumulation; same ids on every test); greedy ids through an fp16 filter + exact fp32 re-evaluation"},
                        "global_batch": BATCH * world, "parallelism": "dp%d (image shards, ids all-gather)" % world, "batches_in_flight_per_gpu": P, "batches_per_vit_launch": VB, "concurrent_decodes": DS if args.mode == "group" else 1,
                        "pipelining": "none" if P == 1 else ("one decode per %d batches (up to %d decodes in flight, one decoder clone and stream each), overlapped with the next batches' ViT (one launch per %d batches) on %d stream(s)" % (P, DS, VB, S)
                                                            if args.mode == "group" else "%d forwards on %d streams" % (P, P))},

@@ -12,6 +12,12 @@ __version__ = "0.1.0"
 # not in bench.py alone -- so that API users, the GPU tests and the benchmark run the same configuration (bench.py reports the
 # effective value in its line; tests/conftest.py sets it as well, before pytest's collection can touch the GPU).
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# Hardware queues: HIP deals the streams of a priority class round-robin onto GPU_MAX_HW_QUEUES = 4 queues, and two streams that share one run
+# one after the other.  The throughput pipeline keeps five streams busy at once (the caller's, stage 1, three decodes); with four queues, which
+# of them aliased depended on creation order, and pipeline.py's timing probe that picks non-aliased streams can misjudge on a busy device
+# (one bench run in ~40 lost 17 % that way).  Eight queues: nothing to alias, same throughput (8.64 against 8.62-8.66 k captions/s).  Same rules
+# as above: read at runtime initialisation, never over the user's own value.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def __getattr__(name):  # lazy: importing the package must not require a GPU or the built library

@@ -1111,6 +1111,9 @@ static hipError_t dec_gemm_s_launch(const void* Ws, float unscale, const float* 
 }
 
 // K = 768 (4 waves x 12 chunks), 512 (4 x 8) or 3072 (4 workgroups x 4 waves x 12, split-K with `ws` / `cnt`)
+#ifndef PIO_DEC_SPLIT_NCG_FC    // column groups (of 16) per workgroup for c_fc / mlp.c_proj in the split-fp16 form
+#define PIO_DEC_SPLIT_NCG_FC 3
+#endif
 #ifndef PIO_DEC_SPLIT_MIN_RG    // 16-row groups from which the layer GEMMs take the split-fp16 form when the split weights exist (5: 65+ prefixes)
 #define PIO_DEC_SPLIT_MIN_RG 5
 #endif
@@ -1120,11 +1123,16 @@ static hipError_t dec_gemm(const float* W, const float* X, int N, int Nout, int 
                            const void* Wsplit = nullptr, float unscale = 0.f) {
   if (N < 1 || N > DEC_MAX_PREFIXES) return hipErrorInvalidValue;
   if constexpr (EPI == DE_STORE || EPI == DE_RESID || EPI == DE_GELU) {
-    if (Wsplit != nullptr && ceil_div(N, 16) >= PIO_DEC_SPLIT_MIN_RG && Nout % 48 == 0) {
-      if (K == 768) return dec_gemm_s_launch<3, 1, EPI, LN>(Wsplit, unscale, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
+    if (Wsplit != nullptr && ceil_div(N, 16) >= PIO_DEC_SPLIT_MIN_RG && Nout % 192 == 0) {
+      // 48 columns per workgroup (12 waves).  64 (16 waves: 192 instead of 256 workgroups for fc / fc2 at 128 prefixes) is 13-16 % slower alone
+      // and measured through the pipeline as PIO_DEC_SPLIT_NCG_FC=4: see profiles/r04_bench_sweep.log
+      if (K == 768) {
+        if (Nout >= 3072) return dec_gemm_s_launch<PIO_DEC_SPLIT_NCG_FC, 1, EPI, LN>(Wsplit, unscale, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
+        return dec_gemm_s_launch<3, 1, EPI, LN>(Wsplit, unscale, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
+      }
       if constexpr (EPI == DE_RESID && !LN) {
         if (K == 3072 && Nout <= 768 && ws != nullptr && cnt != nullptr)
-          return dec_gemm_s_launch<3, 4, EPI, LN>(Wsplit, unscale, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
+          return dec_gemm_s_launch<PIO_DEC_SPLIT_NCG_FC, 4, EPI, LN>(Wsplit, unscale, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
       }
     }
   }

@@ -2,6 +2,7 @@ import os
 import sys
 
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # the configuration patchioner_amd/__init__.py and bench.py run (see there)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import pytest
 
