@@ -33,17 +33,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
-
 // x combined with the lanes 16 / 32 away, without the LDS crossbar (ds_bpermute, ~130 cycles on a serial chain): gfx950's
 // v_permlane16_swap / v_permlane32_swap exchange rows / halves between two registers; fed (x, x) they return (own-or-partner,
 // partner-or-own), and max / + are commutative, so the result is bit-identical to x op __shfl_xor(x, 16 | 32).
@@ -62,6 +51,33 @@ __device__ __forceinline__ float xor16_add(float x) {
 __device__ __forceinline__ float xor32_add(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// Reductions over the 64 lanes, result in every lane.  The butterfly v op= v[lane ^ o], o = 32, 16, 8, 4, 2, 1, WITHOUT the LDS crossbar:
+// __shfl_xor is a ds_bpermute_b32 (~130 cycles each on a serial chain; six of them are 0.4 us, and the decoder's kernels are 5 us long).
+// lane ^ 32 / ^ 16 come from v_permlane32_swap / v_permlane16_swap (above), ^ 8 and ^ 4 from DPP row rotations by 8 and 4 -- a rotation
+// is not an XOR, but once the values agree across ^ 8 (and ^ 4) the lane it reads holds the XOR partner's value -- and ^ 2, ^ 1 from DPP
+// quad permutations.  Same operands, same order of operations: bit-identical to the __shfl_xor form for + and max.
+template <int CTRL> __device__ __forceinline__ float pio_dpp_f32(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = xor32_add(v);
+  v = xor16_add(v);
+  v += pio_dpp_f32<0x128>(v);     // row_ror:8
+  v += pio_dpp_f32<0x124>(v);     // row_ror:4
+  v += pio_dpp_f32<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += pio_dpp_f32<0xB1>(v);      // quad_perm [1,0,3,2]
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = xor32_max(v);
+  v = xor16_max(v);
+  v = fmaxf(v, pio_dpp_f32<0x128>(v));
+  v = fmaxf(v, pio_dpp_f32<0x124>(v));
+  v = fmaxf(v, pio_dpp_f32<0x4E>(v));
+  v = fmaxf(v, pio_dpp_f32<0xB1>(v));
+  return v;
 }
 
 // GELU(v) = 0.5 v (1 + erf(v / sqrt 2)), the exact-erf form DINOv2's MLP uses, to 7.5e-7 absolute (fp32 evaluation,

@@ -305,8 +305,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? PIO_DEC_GEMM_WAVES : 1) void k
     PIO_STAMP(3);
 #endif
     if (LN) {   // row statistics of x: this lane holds 4*CPW values of row 16g+li; sum the 4 kq groups
-      sx += __shfl_xor(sx, 16); sx += __shfl_xor(sx, 32);
-      sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+      sx = xor32_add(xor16_add(sx));            // the other three k-quarters of the row: lanes ^ 16, ^ 32 (v_permlane swaps: same bits as
+      sq = xor32_add(xor16_add(sq));            // the __shfl_xor pair, without two ds_bpermute round trips on the kernel's critical path)
       if (kq == 0) { s_sum[wid][g * 16 + li] = sx; s_sq[wid][g * 16 + li] = sq; }
     }
   }
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void k_dec_attention(const float* __restrict__
           s += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
         }
       }
-      s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+      s += dpp_f32<0xB1>(s); s += dpp_f32<0x4E>(s); s += dpp_f32<0x141>(s);      // lanes ^ 1, ^ 2, ^ 4 (DPP: same bits as the __shfl_xor form)
       if (seg == 0 && j <= pos) s_sc[j] = s * scale;
     }
   }
@@ -765,8 +765,8 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_b(const float* __rest
 #pragma unroll
     for (int g = 0; g < RGB; ++g) {
       float tx = sx[g], tq = sq[g];
-      tx += __shfl_xor(tx, 16); tx += __shfl_xor(tx, 32);
-      tq += __shfl_xor(tq, 16); tq += __shfl_xor(tq, 32);
+      tx = xor32_add(xor16_add(tx));
+      tq = xor32_add(xor16_add(tq));
       if (kq == 0) { s_sum[kw][g * 16 + li] = tx; s_sq[kw][g * 16 + li] = tq; }
     }
   }
@@ -1297,8 +1297,8 @@ __global__ __launch_bounds__(256, 2) void k_lmhead_wide(const float* __restrict_
       tot[g] = sl == 0 ? p : tot[g] + p;
       if (wid == (g & 3)) {
         float tx = sx[g], tq = sq[g];
-        tx += __shfl_xor(tx, 16); tx += __shfl_xor(tx, 32);
-        tq += __shfl_xor(tq, 16); tq += __shfl_xor(tq, 32);
+        tx = xor32_add(xor16_add(tx));
+        tq = xor32_add(xor16_add(tq));
         if (kq == 0) { s_sum[sl * ROWS + g * 16 + li] = tx; s_sq[sl * ROWS + g * 16 + li] = tq; }
       }
     }
