@@ -61,6 +61,9 @@ namespace pio {
 #ifndef PIO_LMF16_WAVES4      // ... at 33..64 prefixes
 #define PIO_LMF16_WAVES4 4
 #endif
+#ifndef PIO_LMF16_CPW8        // 16-column groups per wave of k_lmhead_f16 at 65 .. 128 prefixes (2: half the X~ fragment reads per MFMA, 197 instead of
+#define PIO_LMF16_CPW8 1      // 393 workgroups; measured 6.82 against 6.75 ms per decode(128) and no difference through the pipeline: 1)
+#endif
 #ifndef PIO_LMF16_ABL         // timing ablations of k_lmhead_f16 (diagnostic builds only): 1 no epilogue, 2 no X~ DMA, 3 no MFMA
 #define PIO_LMF16_ABL 0
 #endif
@@ -1408,7 +1411,9 @@ __global__ __launch_bounds__(256) void k_lm_prep(const float* __restrict__ x, in
   }
 }
 
-template <int RG, int NWV>
+// CPW: 16-column groups per wave (a fragment read from the X~ chunk then feeds CPW MFMAs).  Built to test whether the kernel is bound by its LDS
+// fragment reads at 128 rows (16 KB per wave and chunk): it is not -- see PIO_LMF16_CPW8.
+template <int RG, int NWV, int CPW = 1>
 __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_lmhead_f16(const uint16_t* __restrict__ W16, const _Float16* __restrict__ Xh, int N, int V,
                                                        int Vp, const float* __restrict__ stats, const float* __restrict__ dvec,
                                                        const float* __restrict__ cvec, float w_unscale, float* __restrict__ out,
@@ -1418,10 +1423,13 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_lmhead_f16(const
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
-  const int blk = blockIdx.x * NWV + wid;
-  const int j = blk * 16 + li;
-  const int jc = j < V ? j : V - 1;
-  const uint16_t* wp = W16 + (size_t)jc * K + 8 * kq;
+  const int blk0 = (blockIdx.x * NWV + wid) * CPW;      // this wave's first column group
+  const uint16_t* wp[CPW];
+#pragma unroll
+  for (int cgi = 0; cgi < CPW; ++cgi) {
+    const int jj = (blk0 + cgi) * 16 + li;
+    wp[cgi] = W16 + (size_t)(jj < V ? jj : V - 1) * K + 8 * kq;
+  }
   // LDS-DMA pieces of an X~ chunk: 1 KiB = 8 rows x 128 B; pieces wid, wid + NWV, ...
   constexpr int NP = ROWS / 8, PPW = (NP + NWV - 1) / NWV;
   uint32_t xoff[PPW];
@@ -1447,23 +1455,30 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_lmhead_f16(const
   // weights: 2 x 16 B per lane and chunk (k = 64 q + 32 c + 8 kq ..), three chunk sets in flight (inline asm, counted by hand)
 #define PIO_WLOAD(set, q)                                                                                      \
   do {                                                                                                         \
-    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                            \
-      const uint16_t* _p = wp + (q) * CH + 32 * c;                                                             \
+    _Pragma("unroll") for (int c = 0; c < 2 * CPW; ++c) {                                                      \
+      const uint16_t* _p = wp[c >> 1] + (q) * CH + 32 * (c & 1);                                               \
       if constexpr (PIO_LMF16_NT(RG)) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(w[set][c]) : "v"(_p) : "memory"); \
       else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[set][c]) : "v"(_p) : "memory");            \
     }                                                                                                          \
   } while (0)
-#define PIO_WWAIT(set, cnt) asm volatile("s_waitcnt vmcnt(" #cnt ")" : "+v"(w[set][0]), "+v"(w[set][1]) :: "memory")
+#define PIO_WWAIT(set, cnt)                                                                                    \
+  do {                                                                                                         \
+    if constexpr (CPW == 1) asm volatile("s_waitcnt vmcnt(" #cnt ")" : "+v"(w[set][0]), "+v"(w[set][1]) :: "memory");             \
+    else asm volatile("s_waitcnt vmcnt(" #cnt ")" : "+v"(w[set][0]), "+v"(w[set][1]), "+v"(w[set][2 * CPW - 2]), "+v"(w[set][2 * CPW - 1]) :: "memory"); \
+  } while (0)
   // RG >= 4 (64 / 128 prefixes): the X~ chunk is 8 / 16 KB and a chunk's MFMAs last ~0.1 us, far less than an L2 round
   // trip, so one chunk of lookahead left the workgroup waiting on every chunk (50 us for 77 MB at 128 prefixes): ring of
   // DEPTH + 1 buffers and weight sets, DEPTH chunks in flight.  Every wave issues PPW pieces per chunk there (NP % 4 == 0).
-  constexpr bool DEEP = PIO_LMF16_DEEP != 0 && RG >= 4;
+  constexpr bool DEEP = PIO_LMF16_DEEP != 0 && RG >= 4 && CPW == 1;
+  static_assert(CPW == 1 || CPW == 2, "column groups per wave");
   constexpr int DEPTH = DEEP ? 3 : 1, NSET = DEEP ? DEPTH + 1 : 3;
   static_assert(!DEEP || NP % NWV == 0, "uniform vm queue");
-  f32x4 w[NSET][2];
-  f32x4 acc[RG];
+  f32x4 w[NSET][2 * CPW];
+  f32x4 acc[CPW][RG];
 #pragma unroll
-  for (int g = 0; g < RG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int cgi = 0; cgi < CPW; ++cgi)
+#pragma unroll
+    for (int g = 0; g < RG; ++g) acc[cgi][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #define PIO_COMPUTE(q, set, buf)                                                                               \
   do {                                                                                                         \
     const char* xb = lsh + (buf) * XB;                                                                         \
@@ -1471,8 +1486,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_lmhead_f16(const
       _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                          \
         const int row = 16 * g + li;                                                                           \
         const dec_h8 xf = *(const dec_h8*)(xb + row * 128 + (((4 * c + kq) ^ ((row >> 1) & 7)) << 4));         \
-        if (PIO_LMF16_ABL == 3) acc[g][0] += (float)xf[0] * w[set][c][0];                                      \
-        else acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, __builtin_bit_cast(dec_h8, w[set][c]), acc[g], 0, 0, 0); \
+        _Pragma("unroll") for (int cgi = 0; cgi < CPW; ++cgi) {                                                \
+          if (PIO_LMF16_ABL == 3) acc[cgi][g][0] += (float)xf[0] * w[set][2 * cgi + c][0];                    \
+          else acc[cgi][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, __builtin_bit_cast(dec_h8, w[set][2 * cgi + c]), acc[cgi][g], 0, 0, 0); \
+        }                                                                                                      \
       }                                                                                                        \
     }                                                                                                          \
   } while (0)
@@ -1500,7 +1517,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_lmhead_f16(const
     for (int q = 0; q < NCH; ++q) {
       const int r = q % 3;
       // queue per chunk: W(q) | X(q) | W(q+1): W(q), X(q) have landed once only the 2 loads of W(q+1) are outstanding
-      if (q + 1 < NCH) PIO_WWAIT(r, 2);
+      if (q + 1 < NCH) { if constexpr (CPW == 1) PIO_WWAIT(r, 2); else PIO_WWAIT(r, 4); }
       else PIO_WWAIT(r, 0);
       __builtin_amdgcn_s_barrier();
       if (q + 1 < NCH) PIO_XISSUE(q + 1, (q + 1) & 1);
@@ -1520,26 +1537,30 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_lmhead_f16(const
   float4* s_st = (float4*)lsh;
   if (tid < ROWS) s_st[tid] = *(const float4*)(stats + 4 * (tid < N ? tid : N - 1));
   __syncthreads();
-  if (blk * 16 >= V) return;                        // wave-uniform: no columns
-  const float cj = cvec[jc], dj = dvec[jc];
-  if (PIO_LMF16_ABL == 1) {
-    float t = 0.f;
 #pragma unroll
-    for (int g = 0; g < RG; ++g) t += acc[g][0] + acc[g][1] + acc[g][2] + acc[g][3];
-    if (t == 12345.678f) out[j] = t;
-    return;
-  }
+  for (int cgi = 0; cgi < CPW; ++cgi) {
+    const int blk = blk0 + cgi, j = blk * 16 + li, jc = j < V ? j : V - 1;
+    if (blk * 16 >= V) break;                         // wave-uniform: no columns
+    const float cj = cvec[jc], dj = dvec[jc];
+    if (PIO_LMF16_ABL == 1) {
+      float t = 0.f;
 #pragma unroll
-  for (int g = 0; g < RG; ++g)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = 16 * g + 4 * kq + i;
-      const float4 st = s_st[n];
-      const float v = j < V ? st.y * (acc[g][i] * (st.z * w_unscale) - st.x * cj) + dj : -INFINITY;
-      if (n < N && j < V) out[(size_t)n * Vp + j] = v;
-      const float gm = row16_max(v);                // max over the wave's 16 columns (lanes li = 0..15 of this kq group)
-      if (li == 0 && n < N) gmax[(size_t)n * NGp + blk] = gm;
+      for (int g = 0; g < RG; ++g) t += acc[cgi][g][0] + acc[cgi][g][1] + acc[cgi][g][2] + acc[cgi][g][3];
+      if (t == 12345.678f) out[j] = t;
+      continue;
     }
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = 16 * g + 4 * kq + i;
+        const float4 st = s_st[n];
+        const float v = j < V ? st.y * (acc[cgi][g][i] * (st.z * w_unscale) - st.x * cj) + dj : -INFINITY;
+        if (n < N && j < V) out[(size_t)n * Vp + j] = v;
+        const float gm = row16_max(v);                // max over the wave's 16 columns (lanes li = 0..15 of this kq group)
+        if (li == 0 && n < N) gmax[(size_t)n * NGp + blk] = gm;
+      }
+  }
 }
 
 // <= 16 prefixes: k_lm_prep folded into the head (one kernel less per step).  Every workgroup recomputes the rows'
@@ -1738,16 +1759,17 @@ static hipError_t launch_lmhead_f16(const DecoderArgs& a, hipStream_t s) {
   // 128 prefixes (RG = 8): 8 waves = 128 columns per workgroup share an X~ chunk, halving the X~ reads through L2 (77 instead of
   // 154 MB per step); fewer row groups keep 4 waves (two workgroups per CU cover each other's chunk waits)
   constexpr int NWV = RG >= 8 ? PIO_LMF16_WAVES8 : (RG >= 4 ? PIO_LMF16_WAVES4 : 4);
+  constexpr int CPW = RG == 8 ? PIO_LMF16_CPW8 : 1;
   const int Vp = round_up(a.vocab, 64);
   const int smem = (PIO_LMF16_DEEP != 0 && RG >= 4 ? 4 : 2) * RG * 16 * 64 * 2;
   const int NGp = round_up(ceil_div(a.vocab, 16), 64);
   static DeviceOnce attr_once; bool& attr_set = attr_once.flag();
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_lmhead_f16<RG, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)k_lmhead_f16<RG, NWV, CPW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_lmhead_f16<RG, NWV>), dim3(ceil_div(a.vocab, 16 * NWV)), dim3(64 * NWV), smem, s, a.head_w16, (const _Float16*)a.xh, a.N,
+  hipLaunchKernelGGL((k_lmhead_f16<RG, NWV, CPW>), dim3(ceil_div(a.vocab, 16 * NWV * CPW)), dim3(64 * NWV), smem, s, a.head_w16, (const _Float16*)a.xh, a.N,
                      a.vocab, Vp, a.lm_stats, a.head_d, a.head_c, a.head_w16_unscale, a.logits,
                      a.lm_gmax, NGp);
   return hipGetLastError();
