@@ -193,7 +193,7 @@ int main(int argc, char** argv) {
       CK((dec_gemm_s_launch<3, 1, DE_GELU, 1>(s_fc, un, x, N, 4 * E, E, bias, got, cvec, 1e-5f, ws, cnt, s))); cmp("s fc C3", 4 * E);
       hipMemset(ref, 0, (size_t)N * E * 4); hipMemset(got, 0, (size_t)N * E * 4);
       dec_gemm_rg<12, 4, DE_RESID, 0>(w_fc2, hid, N, E, 4 * E, bias, ref, nullptr, nullptr, 0.f, ws, cnt, s);
-      CK((dec_gemm_s_launch<2, 4, DE_RESID, 0>(s_fc2, un, hid, N, E, 4 * E, bias, got, nullptr, 0.f, ws, cnt, s))); cmp("s fc2 C2x4", E);
+      CK((dec_gemm_s_launch<3, 4, DE_RESID, 0>(s_fc2, un, hid, N, E, 4 * E, bias, got, nullptr, 0.f, ws, cnt, s))); cmp("s fc2 C3x4", E);
 #define TS(label, C, KSV, EPIV, LNV, WW, XX, NO, KK, OUT, CV) \
       printf("s %-8s C%d KS%d %7.2f us  (%d wg)\n", label, C, KSV, time_chain([&] { dec_gemm_s_launch<C, KSV, EPIV, LNV>(WW, un, XX, N, NO, KK, bias, OUT, CV, 1e-5f, ws, cnt, s); }), (NO / (16 * C)) * KSV * ((N + 31) / 32))
       TS("qkv", 3, 1, DE_STORE, 1, s_qkv, x, 3 * E, E, qkv, cvec);
