@@ -1012,8 +1012,32 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
     const float4 m4 = *(const float4*)(s_am + w);
     amax = fmaxf(fmaxf(amax, fmaxf(m4.x, m4.y)), fmaxf(m4.z, m4.w));
   }
-  if (!(amax < 32768.f)) {                              // workgroup-uniform; inf lands here too (and stays inf / NaN, as in the fp32 kernels)
-    int e = amax < 3.0e38f ? ilogbf(amax) - 13 : 0;
+  if (!(amax < 32768.f)) {                              // workgroup-uniform
+    if (!(amax < 3.0e38f)) {
+      // an inf among the activations (its row becomes NaN, as in the fp32 kernels) hides the largest FINITE magnitude, which is what
+      // the other rows of the block need the scale for: take the maximum again without the non-finite values
+      __syncthreads();                                  // everyone has read s_am
+      float am = 0.f;
+#pragma unroll 1
+      for (int it = 0; it < NIT; ++it) {
+        const int c = wid + NW * it, row = c / 3, part = c - 3 * row;
+        const int rc = row0 + row < N ? row0 + row : N - 1;
+        const float4 x = *(const float4*)(X + (size_t)rc * K + kbase + 4 * (64 * part + lane));
+        const float a0 = fabsf(x.x * DEC_SPLIT_XS), a1 = fabsf(x.y * DEC_SPLIT_XS), a2 = fabsf(x.z * DEC_SPLIT_XS), a3 = fabsf(x.w * DEC_SPLIT_XS);
+        am = fmaxf(am, fmaxf(fmaxf(a0 < 3.0e38f ? a0 : 0.f, a1 < 3.0e38f ? a1 : 0.f), fmaxf(a2 < 3.0e38f ? a2 : 0.f, a3 < 3.0e38f ? a3 : 0.f)));
+      }
+      am = row16_max(am);
+      am = xor32_max(xor16_max(am));
+      if (lane == 0) s_am[wid] = am;
+      __syncthreads();
+      amax = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w += 4) {
+        const float4 m4 = *(const float4*)(s_am + w);
+        amax = fmaxf(fmaxf(amax, fmaxf(m4.x, m4.y)), fmaxf(m4.z, m4.w));
+      }
+    }
+    int e = amax >= 32768.f ? ilogbf(amax) - 13 : 0;
     e = e < 0 ? 0 : (e > 100 ? 100 : e);
     stage(DEC_SPLIT_XS * ldexpf(1.0f, -e), false);
     unscale *= ldexpf(1.0f, e);

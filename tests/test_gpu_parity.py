@@ -378,7 +378,10 @@ def test_decoder_split_fp16_layer_gemms_take_any_finite_prefix(golden):
         big = x.repeat(-(-96 // x.shape[0]), 1)[:96].clone()
         scales = torch.tensor([1.0, 1e4, 1e-6, 1e8, 3e5, 1.0, 7e6, 1e-3])[torch.arange(96) % 8]
         big *= scales[:, None]
+        big[37] = float("nan")                       # a NaN prefix (an empty box region) decodes to token 0 and leaves its 32-row block alone
+        big[70, 5] = float("inf")
         want = torch.cat([e.decode_greedy(big[i:i + 16])[0].cpu() for i in range(0, 96, 16)])
+        assert (want[37] == 0).all()
         got, _ = e.decode_greedy(big)
         assert np.array_equal(got.cpu().numpy(), want.numpy())
         assert np.array_equal(want[0].numpy(), golden("decoder")["raw_ids"][0])       # the unscaled rows are the golden ones
