@@ -877,7 +877,7 @@ static hipError_t dec_gemm_b_launch(const float* W, const float* X, int N, int N
 // LayerNorm row sums are taken now, once per element instead of once per column-group wave.
 //   grid = (Nout / (16 NCG), KS, ceil(N / 32)), 256 NCG threads: wave (cg, kw) owns 16 columns and the k-steps kw, kw + 4, .. of
 //   the workgroup's 768-k slice; the four k-quarter partials meet in LDS in order, then the epilogues of k_dec_gemm_b.
-static constexpr float DEC_SPLIT_XS = 0.0625f;          // activations are scaled by 2^-4 before the split (|x| < 2^20 stays finite in fp16)
+static constexpr float DEC_SPLIT_XS = 0.0625f;          // the activations' scale before the split: 2^-4 (see the kernel for rows it does not fit)
 __global__ __launch_bounds__(256) void k_dec_split_weights(const float* __restrict__ W, size_t n8, float S, u32x4_t* __restrict__ out) {
   for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < n8; g += (size_t)gridDim.x * 256) {
     const float4 a = *(const float4*)(W + g * 8), b = *(const float4*)(W + g * 8 + 4);
@@ -920,7 +920,7 @@ hipError_t dec_split_weights(const float* W, size_t n, void* out, float* unscale
   int sh = 0;
   if (amax > 0.f) sh = 13 - ilogbf(amax);                       // |W| * 2^sh < 2^14
   const float S = ldexpf(1.0f, sh);
-  *unscale = 1.0f / (S * DEC_SPLIT_XS);
+  *unscale = 1.0f / S;
   e = launch_dec_split_weights(W, n, S, out, s);
   if (e != hipSuccess) return e;
   return hipStreamSynchronize(s);
@@ -952,95 +952,107 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
   const u32x4_t* wp = Ws + ((size_t)j * (K >> 3) + (kbase >> 3) + 4 * kw + kq) * 2;
   u32x4_t wh[6], wl[6];
   // the activations: chunk c = wid + NW it is part c % 3 (64 float4) of row c / 3; split, planes, row sums.
-  // Range: x xscale must stay below fp16's 65504 (v_cvt_pkrtz SATURATES, it does not overflow to inf).  The fixed 2^-4 covers |x| < 2^19;
-  // every wave reports the largest magnitude it staged, and a workgroup that saw more -- never in the decoders' own activations,
-  // but a caller may hand in any finite prefix and the fp32 kernels take it -- stages its slice again with a power-of-two scale
-  // chosen from that maximum (exact; undone in the epilogue).
-  constexpr int XB = NIT % 8 == 0 ? 8 : 6;            // float4 in flight per thread and batch (NIT = 8, 12 or 24)
+  // Scale.  fp16 holds 65504 (and v_cvt_pkrtz SATURATES, it does not overflow to inf) and is normal down to 2^-14: with the fixed
+  // 2^-4 a row keeps its 22 bits when its largest finite magnitude M is in [2^-6, 2^19) -- every activation a GPT-2 style decoder
+  // produces.  Cheap bookkeeping on the way tells whether that can fail; a workgroup where it can -- a caller may hand in any finite
+  // prefix, and the fp32 kernels take it -- stages its slice again, every row with its OWN power of two (M 2^-e in [2^13, 2^14);
+  // inf / NaN elements do not count and make their row NaN, as in the fp32 kernels), undone in the epilogue.  (Per-row scales for
+  // everyone were built first: the second barrier and the conversions waiting behind it cost 2.4 us per kernel; per-chunk maxima in
+  // the fast path 1.6 us: three waves share a SIMD, every VALU instruction here is 12 cycles of it.)
+  constexpr int XB = NIT % 8 == 0 ? 8 : 6;            // float4 in flight per thread and batch (NIT = 8, 12 or 6)
   static_assert(NIT % XB == 0, "whole batches");
+  __shared__ __attribute__((aligned(16))) float s_rmax[ROWS][4];
+  __shared__ float s_rs[ROWS];
   __shared__ __attribute__((aligned(16))) float s_am[16];
-  auto stage = [&](const float xscale, const bool first) {
-    float am = 0.f;
+  float am = 0.f;
+  bool small = false;                                   // wave-uniform
 #pragma unroll
-    for (int b0 = 0; b0 < NIT; b0 += XB) {
-      float4 xs[XB];
+  for (int b0 = 0; b0 < NIT; b0 += XB) {
+    float4 xs[XB];
 #pragma unroll
-      for (int i = 0; i < XB; ++i) {
-        const int c = wid + NW * (b0 + i), row = c / 3, part = c - 3 * row;
-        const int rc = row0 + row < N ? row0 + row : N - 1;
-        xs[i] = *(const float4*)(X + (size_t)rc * K + kbase + 4 * (64 * part + lane));
+    for (int i = 0; i < XB; ++i) {
+      const int c = wid + NW * (b0 + i), row = c / 3, part = c - 3 * row;
+      const int rc = row0 + row < N ? row0 + row : N - 1;
+      xs[i] = *(const float4*)(X + (size_t)rc * K + kbase + 4 * (64 * part + lane));
+    }
+    if (b0 == 0) {          // loads return in order: the first batch of activations (what the split waits for), then the weight stream
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        wh[i] = wp[32 * i];
+        wl[i] = wp[32 * i + 1];
       }
-      if (first && b0 == 0) {   // loads return in order: the first batch of activations (what the split waits for), then the weight stream
-        __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          wh[i] = wp[32 * i];
-          wl[i] = wp[32 * i + 1];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int i = 0; i < XB; ++i) {
-        const int c = wid + NW * (b0 + i), row = c / 3, part = c - 3 * row;
-        const float4 x = xs[i];
-        const float v0 = x.x * xscale, v1 = x.y * xscale, v2 = x.z * xscale, v3 = x.w * xscale;
-        am = fmaxf(fmaxf(am, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));
-        const dec_h2 h01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v0, v1)), h23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v2, v3));
-        const dec_h2 l01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v0 - (float)h01[0]) * 2048.0f, (v1 - (float)h01[1]) * 2048.0f));
-        const dec_h2 l23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v2 - (float)h23[0]) * 2048.0f, (v3 - (float)h23[1]) * 2048.0f));
-        char* const d = lss + row * PSTR + 8 * (64 * part + lane);
-        *(dec_h4*)d = (dec_h4){h01[0], h01[1], h23[0], h23[1]};
-        *(dec_h4*)(d + PLANE) = (dec_h4){l01[0], l01[1], l23[0], l23[1]};
-        if (LN && first) {
-          const float sx = wave_sum_dpp((x.x + x.y) + (x.z + x.w));
-          const float sq = wave_sum_dpp((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w));
-          if (lane == 0) { s_sum[row][part] = sx; s_sq[row][part] = sq; }
-        }
+    for (int i = 0; i < XB; ++i) {
+      const int c = wid + NW * (b0 + i), row = c / 3, part = c - 3 * row;
+      const float4 x = xs[i];
+      const float v0 = x.x * DEC_SPLIT_XS, v1 = x.y * DEC_SPLIT_XS, v2 = x.z * DEC_SPLIT_XS, v3 = x.w * DEC_SPLIT_XS;
+      const dec_h2 h01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v0, v1)), h23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v2, v3));
+      const dec_h2 l01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v0 - (float)h01[0]) * 2048.0f, (v1 - (float)h01[1]) * 2048.0f));
+      const dec_h2 l23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v2 - (float)h23[0]) * 2048.0f, (v3 - (float)h23[1]) * 2048.0f));
+      char* const d = lss + row * PSTR + 8 * (64 * part + lane);
+      *(dec_h4*)d = (dec_h4){h01[0], h01[1], h23[0], h23[1]};
+      *(dec_h4*)(d + PLANE) = (dec_h4){l01[0], l01[1], l23[0], l23[1]};
+      // range bookkeeping, cheap: the largest magnitude this thread has seen (inf included: it sends the workgroup to the careful path,
+      // NaN never wins an fmaxf), and whether some chunk holds values but none of at least 2^-6 (then its row MAY be too small)
+      const float a4 = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+      am = fmaxf(am, a4);
+      small |= __builtin_amdgcn_ballot_w64(a4 >= 0.015625f) == 0ull && __builtin_amdgcn_ballot_w64(a4 > 0.f) != 0ull;
+      if (LN) {
+        const float sx = wave_sum_dpp((x.x + x.y) + (x.z + x.w));
+        const float sq = wave_sum_dpp((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w));
+        if (lane == 0) { s_sum[row][part] = sx; s_sq[row][part] = sq; }
       }
     }
-    if (first) {
-      am = row16_max(am);
-      am = xor32_max(xor16_max(am));
-      if (lane == 0) s_am[wid] = am;
-    }
-  };
-  stage(DEC_SPLIT_XS, true);
-  __syncthreads();
-  float amax = 0.f;
-#pragma unroll
-  for (int w = 0; w < NW; w += 4) {
-    const float4 m4 = *(const float4*)(s_am + w);
-    amax = fmaxf(fmaxf(amax, fmaxf(m4.x, m4.y)), fmaxf(m4.z, m4.w));
   }
-  if (!(amax < 32768.f)) {                              // workgroup-uniform
-    if (!(amax < 3.0e38f)) {
-      // an inf among the activations (its row becomes NaN, as in the fp32 kernels) hides the largest FINITE magnitude, which is what
-      // the other rows of the block need the scale for: take the maximum again without the non-finite values
-      __syncthreads();                                  // everyone has read s_am
-      float am = 0.f;
-#pragma unroll 1
-      for (int it = 0; it < NIT; ++it) {
-        const int c = wid + NW * it, row = c / 3, part = c - 3 * row;
-        const int rc = row0 + row < N ? row0 + row : N - 1;
-        const float4 x = *(const float4*)(X + (size_t)rc * K + kbase + 4 * (64 * part + lane));
-        const float a0 = fabsf(x.x * DEC_SPLIT_XS), a1 = fabsf(x.y * DEC_SPLIT_XS), a2 = fabsf(x.z * DEC_SPLIT_XS), a3 = fabsf(x.w * DEC_SPLIT_XS);
-        am = fmaxf(am, fmaxf(fmaxf(a0 < 3.0e38f ? a0 : 0.f, a1 < 3.0e38f ? a1 : 0.f), fmaxf(a2 < 3.0e38f ? a2 : 0.f, a3 < 3.0e38f ? a3 : 0.f)));
-      }
-      am = row16_max(am);
-      am = xor32_max(xor16_max(am));
-      if (lane == 0) s_am[wid] = am;
-      __syncthreads();
-      amax = 0.f;
+  am = row16_max(am);
+  am = xor32_max(xor16_max(am));
+  if (lane == 0) s_am[wid] = small ? INFINITY : am;     // one word per wave: its largest magnitude, or "look closer"
+  __syncthreads();
+  bool robust;
+  {
+    float hiM = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; w += 4) {
-        const float4 m4 = *(const float4*)(s_am + w);
-        amax = fmaxf(fmaxf(amax, fmaxf(m4.x, m4.y)), fmaxf(m4.z, m4.w));
-      }
+    for (int w = 0; w < NW; w += 4) {
+      const float4 m4 = *(const float4*)(s_am + w);
+      hiM = fmaxf(fmaxf(hiM, fmaxf(m4.x, m4.y)), fmaxf(m4.z, m4.w));
     }
-    int e = amax >= 32768.f ? ilogbf(amax) - 13 : 0;
-    e = e < 0 ? 0 : (e > 100 ? 100 : e);
-    stage(DEC_SPLIT_XS * ldexpf(1.0f, -e), false);
-    unscale *= ldexpf(1.0f, e);
+    robust = !(hiM < 32768.f / DEC_SPLIT_XS);           // workgroup-uniform
+  }
+  if (robust) {
+#pragma unroll 1
+    for (int it = 0; it < NIT; ++it) {                    // the rows' largest FINITE magnitudes
+      const int c = wid + NW * it, row = c / 3, part = c - 3 * row;
+      const int rc = row0 + row < N ? row0 + row : N - 1;
+      const float4 x = *(const float4*)(X + (size_t)rc * K + kbase + 4 * (64 * part + lane));
+      const float a0 = fabsf(x.x), a1 = fabsf(x.y), a2 = fabsf(x.z), a3 = fabsf(x.w);
+      float m = fmaxf(fmaxf(a0 < 3.0e38f ? a0 : 0.f, a1 < 3.0e38f ? a1 : 0.f), fmaxf(a2 < 3.0e38f ? a2 : 0.f, a3 < 3.0e38f ? a3 : 0.f));
+      m = row16_max(m);
+      m = xor32_max(xor16_max(m));
+      if (lane == 0) s_rmax[row][part] = m;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < NIT; ++it) {
+      const int c = wid + NW * it, row = c / 3, part = c - 3 * row;
+      const int rc = row0 + row < N ? row0 + row : N - 1;
+      const float4 x = *(const float4*)(X + (size_t)rc * K + kbase + 4 * (64 * part + lane));
+      const float4 m4 = *(const float4*)s_rmax[row];
+      const float m = fmaxf(fmaxf(m4.x, m4.y), m4.z);
+      int e = m > 0.f ? ilogbf(m) - 13 : 0;               // m 2^-e in [2^13, 2^14)
+      e = e < -100 ? -100 : e;
+      const float sc = ldexpf(1.0f, -e);
+      if (part == 0 && lane == 0) s_rs[row] = ldexpf(1.0f, e);
+      const float v0 = x.x * sc, v1 = x.y * sc, v2 = x.z * sc, v3 = x.w * sc;
+      const dec_h2 h01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v0, v1)), h23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v2, v3));
+      const dec_h2 l01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v0 - (float)h01[0]) * 2048.0f, (v1 - (float)h01[1]) * 2048.0f));
+      const dec_h2 l23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v2 - (float)h23[0]) * 2048.0f, (v3 - (float)h23[1]) * 2048.0f));
+      char* const d = lss + row * PSTR + 8 * (64 * part + lane);
+      *(dec_h4*)d = (dec_h4){h01[0], h01[1], h23[0], h23[1]};
+      *(dec_h4*)(d + PLANE) = (dec_h4){l01[0], l01[1], l23[0], l23[1]};
+    }
     __syncthreads();
   }
   f32x4 a0[RGB], a1[RGB];
@@ -1061,10 +1073,20 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
   }
   const float bj = bias[j];
   const float cj = LN ? cvec[j] : 0.f;
+  float rsc[RGB][4];                                // scales of this lane's accumulator rows
+#pragma unroll
+  for (int g = 0; g < RGB; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rsc[g][i] = robust ? s_rs[16 * g + 4 * kq + i] : 1.0f / DEC_SPLIT_XS;
   __syncthreads();                                  // every wave is done with the planes: reuse them for the partial tiles
   float* const lsm = (float*)lss;
 #pragma unroll
-  for (int g = 0; g < RGB; ++g) *(f32x4*)(lsm + ((wid * RGB + g) * 64 + lane) * 4) = (a0[g] + a1[g] * (1.0f / 2048.0f)) * unscale;
+  for (int g = 0; g < RGB; ++g) {
+    f32x4 t = (a0[g] + a1[g] * (1.0f / 2048.0f)) * unscale;         // unscale: the weights' scale; the row's own one (a power of two) follows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] *= rsc[g][i];
+    *(f32x4*)(lsm + ((wid * RGB + g) * 64 + lane) * 4) = t;
+  }
   __syncthreads();
   const int g = kw;
   const bool fin = kw < RGB;                        // wave-uniform: wave (cg, kw < 2) finishes row group kw of its column group

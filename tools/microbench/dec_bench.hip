@@ -180,7 +180,7 @@ int main(int argc, char** argv) {
     {  // split-fp16 form (k_dec_gemm_s): weights split once, S = the power of two that puts max |w| into [2^13, 2^14)
       void *s_qkv, *s_proj, *s_fc, *s_fc2;
       CK(hipMalloc(&s_qkv, (size_t)3 * E * E * 4)); CK(hipMalloc(&s_proj, (size_t)E * E * 4)); CK(hipMalloc(&s_fc, (size_t)4 * E * E * 4)); CK(hipMalloc(&s_fc2, (size_t)4 * E * E * 4));
-      const float S = 524288.f, un = 1.0f / (S * DEC_SPLIT_XS);
+      const float S = 524288.f, un = 1.0f / S;
       CK(launch_dec_split_weights(w_qkv, (size_t)3 * E * E, S, s_qkv, s)); CK(launch_dec_split_weights(w_proj, (size_t)E * E, S, s_proj, s));
       CK(launch_dec_split_weights(w_fc, (size_t)4 * E * E, S, s_fc, s)); CK(launch_dec_split_weights(w_fc2, (size_t)4 * E * E, S, s_fc2, s));
       CK(hipMemcpy(x, h.data(), (size_t)N * E * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(hid, h.data(), (size_t)N * 4 * E * 4, hipMemcpyHostToDevice));
@@ -188,7 +188,7 @@ int main(int argc, char** argv) {
       CK((dec_gemm_s_launch<3, 1, DE_STORE, 1>(s_qkv, un, x, N, 3 * E, E, bias, got, cvec, 1e-5f, ws, cnt, s))); cmp("s qkv C3", 3 * E);
       CK((dec_gemm_s_launch<2, 1, DE_STORE, 1>(s_qkv, un, x, N, 3 * E, E, bias, got, cvec, 1e-5f, ws, cnt, s))); cmp("s qkv C2", 3 * E);
       dec_gemm_rg<12, 1, DE_STORE, 0>(w_proj, att, N, E, E, bias, ref, nullptr, nullptr, 0.f, nullptr, nullptr, s);
-      CK((dec_gemm_s_launch<1, 1, DE_STORE, 0>(s_proj, un, att, N, E, E, bias, got, nullptr, 0.f, ws, cnt, s))); cmp("s proj C1", E);
+      CK((dec_gemm_s_launch<3, 1, DE_STORE, 0>(s_proj, un, att, N, E, E, bias, got, nullptr, 0.f, ws, cnt, s))); cmp("s proj C3", E);
       dec_gemm_rg<12, 1, DE_GELU, 1>(w_fc, x, N, 4 * E, E, bias, ref, nullptr, cvec, 1e-5f, nullptr, nullptr, s);
       CK((dec_gemm_s_launch<3, 1, DE_GELU, 1>(s_fc, un, x, N, 4 * E, E, bias, got, cvec, 1e-5f, ws, cnt, s))); cmp("s fc C3", 4 * E);
       hipMemset(ref, 0, (size_t)N * E * 4); hipMemset(got, 0, (size_t)N * E * 4);
@@ -198,13 +198,10 @@ int main(int argc, char** argv) {
       printf("s %-8s C%d KS%d %7.2f us  (%d wg)\n", label, C, KSV, time_chain([&] { dec_gemm_s_launch<C, KSV, EPIV, LNV>(WW, un, XX, N, NO, KK, bias, OUT, CV, 1e-5f, ws, cnt, s); }), (NO / (16 * C)) * KSV * ((N + 31) / 32))
       TS("qkv", 3, 1, DE_STORE, 1, s_qkv, x, 3 * E, E, qkv, cvec);
       TS("qkv", 2, 1, DE_STORE, 1, s_qkv, x, 3 * E, E, qkv, cvec);
-      TS("qkv", 1, 1, DE_STORE, 1, s_qkv, x, 3 * E, E, qkv, cvec);
-      TS("proj", 1, 1, DE_RESID, 0, s_proj, att, E, E, x, nullptr);
       TS("proj", 2, 1, DE_RESID, 0, s_proj, att, E, E, x, nullptr);
       TS("fc", 3, 1, DE_GELU, 1, s_fc, x, 4 * E, E, hid, cvec);
       TS("fc", 2, 1, DE_GELU, 1, s_fc, x, 4 * E, E, hid, cvec);
       TS("fc2", 2, 4, DE_RESID, 0, s_fc2, hid, E, 4 * E, x, nullptr);
-      TS("fc2", 1, 4, DE_RESID, 0, s_fc2, hid, E, 4 * E, x, nullptr);
       TS("fc2", 3, 4, DE_RESID, 0, s_fc2, hid, E, 4 * E, x, nullptr);
       TS("qkv", 4, 1, DE_STORE, 1, s_qkv, x, 3 * E, E, qkv, cvec);
       TS("fc", 4, 1, DE_GELU, 1, s_fc, x, 4 * E, E, hid, cvec);
