@@ -877,7 +877,7 @@ static hipError_t dec_gemm_b_launch(const float* W, const float* X, int N, int N
 // LayerNorm row sums are taken now, once per element instead of once per column-group wave.
 //   grid = (Nout / (16 NCG), KS, ceil(N / 32)), 256 NCG threads: wave (cg, kw) owns 16 columns and the k-steps kw, kw + 4, .. of
 //   the workgroup's 768-k slice; the four k-quarter partials meet in LDS in order, then the epilogues of k_dec_gemm_b.
-static constexpr float DEC_SPLIT_XS = 0.0625f;          // the activations' scale before the split: 2^-4 (see the kernel for rows it does not fit)
+static constexpr float DEC_SPLIT_XS = 1.0f;             // the activations' scale before the split (1: no multiply; see the kernel for rows it does not fit)
 __global__ __launch_bounds__(256) void k_dec_split_weights(const float* __restrict__ W, size_t n8, float S, u32x4_t* __restrict__ out) {
   for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < n8; g += (size_t)gridDim.x * 256) {
     const float4 a = *(const float4*)(W + g * 8), b = *(const float4*)(W + g * 8 + 4);
@@ -952,9 +952,9 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
   const u32x4_t* wp = Ws + ((size_t)j * (K >> 3) + (kbase >> 3) + 4 * kw + kq) * 2;
   u32x4_t wh[6], wl[6];
   // the activations: chunk c = wid + NW it is part c % 3 (64 float4) of row c / 3; split, planes, row sums.
-  // Scale.  fp16 holds 65504 (and v_cvt_pkrtz SATURATES, it does not overflow to inf) and is normal down to 2^-14: with the fixed
-  // 2^-4 a row keeps its 22 bits when its largest finite magnitude M is in [2^-6, 2^19) -- every activation a GPT-2 style decoder
-  // produces.  Cheap bookkeeping on the way tells whether that can fail; a workgroup where it can -- a caller may hand in any finite
+  // Scale.  fp16 holds 65504 (and v_cvt_pkrtz SATURATES, it does not overflow to inf) and is normal down to 2^-14: split as it is, a
+  // row keeps its 22 bits when its largest finite magnitude M is in [2^-10, 2^15) -- every activation a GPT-2 style decoder produces
+  // (the residual stream's outlier channels reach a few thousand).  Cheap bookkeeping on the way tells whether that can fail; a workgroup where it can -- a caller may hand in any finite
   // prefix, and the fp32 kernels take it -- stages its slice again, every row with its OWN power of two (M 2^-e in [2^13, 2^14);
   // inf / NaN elements do not count and make their row NaN, as in the fp32 kernels), undone in the epilogue.  (Per-row scales for
   // everyone were built first: the second barrier and the conversions waiting behind it cost 2.4 us per kernel; per-chunk maxima in
@@ -988,7 +988,8 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
     for (int i = 0; i < XB; ++i) {
       const int c = wid + NW * (b0 + i), row = c / 3, part = c - 3 * row;
       const float4 x = xs[i];
-      const float v0 = x.x * DEC_SPLIT_XS, v1 = x.y * DEC_SPLIT_XS, v2 = x.z * DEC_SPLIT_XS, v3 = x.w * DEC_SPLIT_XS;
+      static_assert(DEC_SPLIT_XS == 1.0f, "the fast path splits x itself");
+      const float v0 = x.x, v1 = x.y, v2 = x.z, v3 = x.w;
       const dec_h2 h01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v0, v1)), h23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v2, v3));
       const dec_h2 l01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v0 - (float)h01[0]) * 2048.0f, (v1 - (float)h01[1]) * 2048.0f));
       const dec_h2 l23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v2 - (float)h23[0]) * 2048.0f, (v3 - (float)h23[1]) * 2048.0f));
@@ -999,7 +1000,8 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
       // NaN never wins an fmaxf), and whether some chunk holds values but none of at least 2^-6 (then its row MAY be too small)
       const float a4 = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
       am = fmaxf(am, a4);
-      small |= __builtin_amdgcn_ballot_w64(a4 >= 0.015625f) == 0ull && __builtin_amdgcn_ballot_w64(a4 > 0.f) != 0ull;
+      // (2^-10: see above)
+      small |= __builtin_amdgcn_ballot_w64(a4 >= 0.0009765625f) == 0ull && __builtin_amdgcn_ballot_w64(a4 > 0.f) != 0ull;
       if (LN) {
         const float sx = wave_sum_dpp((x.x + x.y) + (x.z + x.w));
         const float sq = wave_sum_dpp((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w));
@@ -1019,7 +1021,7 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
       const float4 m4 = *(const float4*)(s_am + w);
       hiM = fmaxf(fmaxf(hiM, fmaxf(m4.x, m4.y)), fmaxf(m4.z, m4.w));
     }
-    robust = !(hiM < 32768.f / DEC_SPLIT_XS);           // workgroup-uniform
+    robust = !(hiM < 32768.f);                          // workgroup-uniform
   }
   if (robust) {
 #pragma unroll 1
@@ -1119,6 +1121,7 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
     }
   }
   if (!fin) return;
+  const float rK = 1.0f / (float)K;                 // (a multiplication per row instead of an IEEE division sequence: this kernel's sums are its own anyway)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rr = g * 16 + 4 * kq + i, n = row0 + rr;
@@ -1127,8 +1130,8 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
     if (LN) {
       const float tx = (s_sum[rr][0] + s_sum[rr][1]) + s_sum[rr][2];
       const float tq = (s_sq[rr][0] + s_sq[rr][1]) + s_sq[rr][2];
-      const float mu = tx / (float)K;
-      const float var = fmaxf(tq / (float)K - mu * mu, 0.f);
+      const float mu = tx * rK;
+      const float var = fmaxf(tq * rK - mu * mu, 0.f);
       v = rsqrtf(var + eps) * (s[i] - mu * cj) + bj;
     } else {
       v = s[i] + bj;
