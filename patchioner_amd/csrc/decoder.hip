@@ -966,6 +966,55 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
   __shared__ __attribute__((aligned(16))) float s_am[16];
   float am = 0.f;
   bool small = false;                                   // wave-uniform
+  if constexpr (LN) {
+    // LayerNorm consumers: a wave stages WHOLE rows (row wid, wid + NW, ..: three float4 per lane and row), so that the row sums are one
+    // reduction pair per row instead of one per 64-lane chunk (16 of them per thread were a third of this phase's VALU work, and with three
+    // waves on a SIMD every VALU instruction of it is 12 cycles); the last waves stage one row less
+    constexpr int RPW = (ROWS + NW - 1) / NW;
+    float4 xr[RPW][3];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int row = wid + NW * i;
+      if (row < ROWS) {                                   // wave-uniform
+        const int rc = row0 + row < N ? row0 + row : N - 1;
+#pragma unroll
+        for (int part = 0; part < 3; ++part) xr[i][part] = *(const float4*)(X + (size_t)rc * K + kbase + 4 * (64 * part + lane));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                    // loads return in order: the activations first, then the weight stream
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      wh[i] = wp[32 * i];
+      wl[i] = wp[32 * i + 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int row = wid + NW * i;
+      if (row < ROWS) {
+        float sx = 0.f, sq = 0.f;
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+          const float4 x = xr[i][part];
+          const float v0 = x.x, v1 = x.y, v2 = x.z, v3 = x.w;
+          const dec_h2 h01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v0, v1)), h23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v2, v3));
+          const dec_h2 l01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v0 - (float)h01[0]) * 2048.0f, (v1 - (float)h01[1]) * 2048.0f));
+          const dec_h2 l23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v2 - (float)h23[0]) * 2048.0f, (v3 - (float)h23[1]) * 2048.0f));
+          char* const d = lss + row * PSTR + 8 * (64 * part + lane);
+          *(dec_h4*)d = (dec_h4){h01[0], h01[1], h23[0], h23[1]};
+          *(dec_h4*)(d + PLANE) = (dec_h4){l01[0], l01[1], l23[0], l23[1]};
+          const float a4 = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+          am = fmaxf(am, a4);
+          small |= __builtin_amdgcn_ballot_w64(a4 >= 0.0009765625f) == 0ull && __builtin_amdgcn_ballot_w64(a4 > 0.f) != 0ull;
+          sx += (x.x + x.y) + (x.z + x.w);
+          sq += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+        }
+        sx = wave_sum_dpp(sx);
+        sq = wave_sum_dpp(sq);
+        if (lane == 0) { s_sum[row][0] = sx; s_sum[row][1] = 0.f; s_sum[row][2] = 0.f; s_sq[row][0] = sq; s_sq[row][1] = 0.f; s_sq[row][2] = 0.f; }
+      }
+    }
+  } else {
 #pragma unroll
   for (int b0 = 0; b0 < NIT; b0 += XB) {
     float4 xs[XB];
@@ -1008,6 +1057,7 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
         if (lane == 0) { s_sum[row][part] = sx; s_sq[row][part] = sq; }
       }
     }
+  }
   }
   am = row16_max(am);
   am = xor32_max(xor16_max(am));
