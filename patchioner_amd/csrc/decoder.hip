@@ -992,7 +992,7 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
     for (int i = 0; i < RPW; ++i) {
       const int row = wid + NW * i;
       if (row < ROWS) {
-        float sx = 0.f, sq = 0.f;
+        float sx = 0.f, sq = 0.f, ra = 0.f;
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
           const float4 x = xr[i][part];
@@ -1003,12 +1003,12 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
           char* const d = lss + row * PSTR + 8 * (64 * part + lane);
           *(dec_h4*)d = (dec_h4){h01[0], h01[1], h23[0], h23[1]};
           *(dec_h4*)(d + PLANE) = (dec_h4){l01[0], l01[1], l23[0], l23[1]};
-          const float a4 = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
-          am = fmaxf(am, a4);
-          small |= __builtin_amdgcn_ballot_w64(a4 >= 0.0009765625f) == 0ull && __builtin_amdgcn_ballot_w64(a4 > 0.f) != 0ull;
+          ra = fmaxf(ra, fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))));
           sx += (x.x + x.y) + (x.z + x.w);
           sq += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
         }
+        am = fmaxf(am, ra);
+        small |= __builtin_amdgcn_ballot_w64(ra >= 0.0009765625f) == 0ull && __builtin_amdgcn_ballot_w64(ra > 0.f) != 0ull;   // per ROW here
         sx = wave_sum_dpp(sx);
         sq = wave_sum_dpp(sq);
         if (lane == 0) { s_sum[row][0] = sx; s_sum[row][1] = 0.f; s_sum[row][2] = 0.f; s_sq[row][0] = sq; s_sq[row][1] = 0.f; s_sq[row][2] = 0.f; }
