@@ -20,6 +20,9 @@
 //     stream in place; mlp.c_proj (K = 3072) is split over 4 workgroups per column group whose partial tiles
 //     are summed in slice order by the last arriver (ticket counter, agent-scope release/acquire):
 //     deterministic, no floating-point atomics.
+//   * above 64 prefixes (round 4) the three wide layer GEMMs run on split-fp16 operands (k_dec_gemm_s: fp16 hi / lo pairs, three
+//     v_mfma_f32_16x16x32_f16 per product, fp32-class accuracy): at that size the fp32 matrix pipe, 256 flop / clk / CU, is what a
+//     workgroup spends its residency on.
 //   * the LM head never materialises logits: each workgroup reduces its 16 columns to (max, arg-max,
 //     sum-exp) per prefix and k_dec_select merges the 3142 partials into the id / log-prob and writes the
 //     next input embedding.
