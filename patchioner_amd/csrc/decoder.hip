@@ -934,6 +934,24 @@ hipError_t launch_dec_split_weights(const float* W, size_t n, float S, void* out
   return hipGetLastError();
 }
 
+// x (4 floats) -> hi = fp16 toward zero, lo' = fp16((x - hi) 2^11): x 2^11 - hi 2^11 is exact in one FMA (hi is x cut to 11 bits), and the
+// hi operand rides in as fp16 (v_fma_mix_f32): a multiply and an FMA per element instead of convert, subtract, multiply.
+__device__ __forceinline__ void dec_split4(const float4 x, const float s, dec_h4& hi, dec_h4& lo) {
+  const float v0 = x.x * s, v1 = x.y * s, v2 = x.z * s, v3 = x.w * s;
+  const dec_h2 h01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v0, v1)), h23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v2, v3));
+  const float l0 = __builtin_fmaf((float)h01[0], -2048.0f, v0 * 2048.0f), l1 = __builtin_fmaf((float)h01[1], -2048.0f, v1 * 2048.0f);
+  const float l2 = __builtin_fmaf((float)h23[0], -2048.0f, v2 * 2048.0f), l3 = __builtin_fmaf((float)h23[1], -2048.0f, v3 * 2048.0f);
+  const dec_h2 l01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(l0, l1)), l23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(l2, l3));
+  hi = (dec_h4){h01[0], h01[1], h23[0], h23[1]};
+  lo = (dec_h4){l01[0], l01[1], l23[0], l23[1]};
+}
+// the largest |hi| of four halfs, as two packed fp16 maxima (an fp16 inf for an fp32 inf; NaN never wins a maximum)
+__device__ __forceinline__ dec_h2 dec_absmax4(const dec_h4 hi, const dec_h2 run) {
+  const uint2 b = __builtin_bit_cast(uint2, hi);
+  const dec_h2 a = __builtin_bit_cast(dec_h2, b.x & 0x7fff7fffu), c = __builtin_bit_cast(dec_h2, b.y & 0x7fff7fffu);
+  return __builtin_elementwise_max(__builtin_elementwise_max(a, c), run);
+}
+
 template <int NCG, int KS, int EPI, int LN>
 __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __restrict__ Ws, const float* __restrict__ X, int N, int Nout, int K,
                                                              const float* __restrict__ bias, float* out, const float* __restrict__ cvec,
@@ -995,21 +1013,21 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
     for (int i = 0; i < RPW; ++i) {
       const int row = wid + NW * i;
       if (row < ROWS) {
-        float sx = 0.f, sq = 0.f, ra = 0.f;
+        float sx = 0.f, sq = 0.f;
+        dec_h2 ra2 = (dec_h2){(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
           const float4 x = xr[i][part];
-          const float v0 = x.x, v1 = x.y, v2 = x.z, v3 = x.w;
-          const dec_h2 h01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v0, v1)), h23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v2, v3));
-          const dec_h2 l01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v0 - (float)h01[0]) * 2048.0f, (v1 - (float)h01[1]) * 2048.0f));
-          const dec_h2 l23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v2 - (float)h23[0]) * 2048.0f, (v3 - (float)h23[1]) * 2048.0f));
+          dec_h4 hi, lo;
+          dec_split4(x, 1.0f, hi, lo);
           char* const d = lss + row * PSTR + 8 * (64 * part + lane);
-          *(dec_h4*)d = (dec_h4){h01[0], h01[1], h23[0], h23[1]};
-          *(dec_h4*)(d + PLANE) = (dec_h4){l01[0], l01[1], l23[0], l23[1]};
-          ra = fmaxf(ra, fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))));
+          *(dec_h4*)d = hi;
+          *(dec_h4*)(d + PLANE) = lo;
+          ra2 = dec_absmax4(hi, ra2);
           sx += (x.x + x.y) + (x.z + x.w);
           sq += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
         }
+        const float ra = fmaxf((float)ra2[0], (float)ra2[1]);
         am = fmaxf(am, ra);
         small |= __builtin_amdgcn_ballot_w64(ra >= 0.0009765625f) == 0ull && __builtin_amdgcn_ballot_w64(ra > 0.f) != 0ull;   // per ROW here
         sx = wave_sum_dpp(sx);
@@ -1041,18 +1059,18 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
       const int c = wid + NW * (b0 + i), row = c / 3, part = c - 3 * row;
       const float4 x = xs[i];
       static_assert(DEC_SPLIT_XS == 1.0f, "the fast path splits x itself");
-      const float v0 = x.x, v1 = x.y, v2 = x.z, v3 = x.w;
-      const dec_h2 h01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v0, v1)), h23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v2, v3));
-      const dec_h2 l01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v0 - (float)h01[0]) * 2048.0f, (v1 - (float)h01[1]) * 2048.0f));
-      const dec_h2 l23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v2 - (float)h23[0]) * 2048.0f, (v3 - (float)h23[1]) * 2048.0f));
+      dec_h4 hi, lo;
+      dec_split4(x, 1.0f, hi, lo);
       char* const d = lss + row * PSTR + 8 * (64 * part + lane);
-      *(dec_h4*)d = (dec_h4){h01[0], h01[1], h23[0], h23[1]};
-      *(dec_h4*)(d + PLANE) = (dec_h4){l01[0], l01[1], l23[0], l23[1]};
+      *(dec_h4*)d = hi;
+      *(dec_h4*)(d + PLANE) = lo;
       // range bookkeeping, cheap: the largest magnitude this thread has seen (inf included: it sends the workgroup to the careful path,
       // NaN never wins an fmaxf), and whether some chunk holds values but none of at least 2^-6 (then its row MAY be too small)
-      const float a4 = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+      const dec_h2 c2 = dec_absmax4(hi, (dec_h2){(_Float16)0.f, (_Float16)0.f});
+      const float a4 = fmaxf((float)c2[0], (float)c2[1]);
       am = fmaxf(am, a4);
-      // (2^-10: see above)
+      // (2^-10: see above; fc2 / proj add into the residual stream, where the ABSOLUTE error counts and is 2^-35 whatever the row's size, so a
+      //  "small" chunk only costs them the careful path)
       small |= __builtin_amdgcn_ballot_w64(a4 >= 0.0009765625f) == 0ull && __builtin_amdgcn_ballot_w64(a4 > 0.f) != 0ull;
       if (LN) {
         const float sx = wave_sum_dpp((x.x + x.y) + (x.z + x.w));
@@ -1100,13 +1118,11 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
       e = e < -100 ? -100 : e;
       const float sc = ldexpf(1.0f, -e);
       if (part == 0 && lane == 0) s_rs[row] = ldexpf(1.0f, e);
-      const float v0 = x.x * sc, v1 = x.y * sc, v2 = x.z * sc, v3 = x.w * sc;
-      const dec_h2 h01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v0, v1)), h23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v2, v3));
-      const dec_h2 l01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v0 - (float)h01[0]) * 2048.0f, (v1 - (float)h01[1]) * 2048.0f));
-      const dec_h2 l23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz((v2 - (float)h23[0]) * 2048.0f, (v3 - (float)h23[1]) * 2048.0f));
+      dec_h4 hi, lo;
+      dec_split4(x, sc, hi, lo);
       char* const d = lss + row * PSTR + 8 * (64 * part + lane);
-      *(dec_h4*)d = (dec_h4){h01[0], h01[1], h23[0], h23[1]};
-      *(dec_h4*)(d + PLANE) = (dec_h4){l01[0], l01[1], l23[0], l23[1]};
+      *(dec_h4*)d = hi;
+      *(dec_h4*)(d + PLANE) = lo;
     }
     __syncthreads();
   }
