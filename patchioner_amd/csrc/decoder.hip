@@ -37,6 +37,9 @@ namespace pio {
 #ifndef PIO_DABL_NOX
 #define PIO_DABL_NOX 0
 #endif
+#ifndef PIO_DABL_NOSPLIT     // 1: k_dec_gemm_s stages its activations without the split arithmetic and the row sums
+#define PIO_DABL_NOSPLIT 0
+#endif
 #ifndef PIO_DABL_NOMFMA      // 2: every fp32 MFMA of this file on a 2-pass instruction (a quarter of the pipe time, same dataflow); 1: only the first sixth of every layer GEMM's fp32 MFMAs is issued (what a split-fp16 form would cost the matrix pipe: 3 / 16)
 #define PIO_DABL_NOMFMA 0
 #endif
@@ -937,6 +940,11 @@ hipError_t launch_dec_split_weights(const float* W, size_t n, float S, void* out
 // x (4 floats) -> hi = fp16 toward zero, lo' = fp16((x - hi) 2^11): x 2^11 - hi 2^11 is exact in one FMA (hi is x cut to 11 bits), and the
 // hi operand rides in as fp16 (v_fma_mix_f32): a multiply and an FMA per element instead of convert, subtract, multiply.
 __device__ __forceinline__ void dec_split4(const float4 x, const float s, dec_h4& hi, dec_h4& lo) {
+#if PIO_DABL_NOSPLIT       // timing ablation: the staging without its arithmetic (what planes written by the PRODUCERS would leave); wrong results
+  hi = __builtin_bit_cast(dec_h4, make_float2(x.x, x.y));
+  lo = __builtin_bit_cast(dec_h4, make_float2(x.z, x.w));
+  return;
+#endif
   const float v0 = x.x * s, v1 = x.y * s, v2 = x.z * s, v3 = x.w * s;
   const dec_h2 h01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v0, v1)), h23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v2, v3));
   const float l0 = __builtin_fmaf((float)h01[0], -2048.0f, v0 * 2048.0f), l1 = __builtin_fmaf((float)h01[1], -2048.0f, v1 * 2048.0f);
@@ -1014,6 +1022,7 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
       const int row = wid + NW * i;
       if (row < ROWS) {
         float sx = 0.f, sq = 0.f;
+        const float x_dummy = 1.0f;
         dec_h2 ra2 = (dec_h2){(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
@@ -1024,14 +1033,18 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
           *(dec_h4*)d = hi;
           *(dec_h4*)(d + PLANE) = lo;
           ra2 = dec_absmax4(hi, ra2);
-          sx += (x.x + x.y) + (x.z + x.w);
-          sq += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+          if (!PIO_DABL_NOSPLIT) {
+            sx += (x.x + x.y) + (x.z + x.w);
+            sq += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+          }
         }
         const float ra = fmaxf((float)ra2[0], (float)ra2[1]);
         am = fmaxf(am, ra);
         small |= __builtin_amdgcn_ballot_w64(ra >= 0.0009765625f) == 0ull && __builtin_amdgcn_ballot_w64(ra > 0.f) != 0ull;   // per ROW here
-        sx = wave_sum_dpp(sx);
-        sq = wave_sum_dpp(sq);
+        if (!PIO_DABL_NOSPLIT) {
+          sx = wave_sum_dpp(sx);
+          sq = wave_sum_dpp(sq);
+        } else { sx = x_dummy; sq = 768.f; }
         if (lane == 0) { s_sum[row][0] = sx; s_sum[row][1] = 0.f; s_sum[row][2] = 0.f; s_sq[row][0] = sq; s_sq[row][1] = 0.f; s_sq[row][2] = 0.f; }
       }
     }
