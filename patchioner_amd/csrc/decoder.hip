@@ -960,13 +960,14 @@ __device__ __forceinline__ dec_h2 dec_absmax4(const dec_h4 hi, const dec_h2 run)
   return __builtin_elementwise_max(__builtin_elementwise_max(a, c), run);
 }
 
-template <int NCG, int KS, int EPI, int LN>
+template <int NCG, int KS, int EPI, int LN, int RGB = 2>
 __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __restrict__ Ws, const float* __restrict__ X, int N, int Nout, int K,
                                                              const float* __restrict__ bias, float* out, const float* __restrict__ cvec,
                                                              float eps, float unscale, float* ws, unsigned* cnt) {
   static_assert(!(LN && KS > 1), "LayerNorm row sums need the whole row in one workgroup");
-  constexpr int NW = 4 * NCG, ROWS = 32, RGB = 2, PSTR = 768 * 2 + 16, PLANE = ROWS * PSTR, NIT = 96 / NW;
-  static_assert(NIT * NW == 96, "a row is three 64-lane chunks: 96 chunks must divide among the waves");
+  constexpr int NW = 4 * NCG, ROWS = 16 * RGB, PSTR = 768 * 2 + 16, PLANE = ROWS * PSTR, NIT = 3 * ROWS / NW;
+  static_assert(RGB == 1 || RGB == 2, "16 or 32 rows per workgroup");
+  static_assert(NIT * NW == 3 * ROWS, "a row is three 64-lane chunks: they must divide among the waves");
   extern __shared__ __attribute__((aligned(16))) char lss[];       // hi plane, lo plane; afterwards partial tiles [NW][RGB][256] fp32
   __shared__ float s_sum[LN ? ROWS : 1][3], s_sq[LN ? ROWS : 1][3];
   __shared__ int s_last;
@@ -988,7 +989,7 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
   // inf / NaN elements do not count and make their row NaN, as in the fp32 kernels), undone in the epilogue.  (Per-row scales for
   // everyone were built first: the second barrier and the conversions waiting behind it cost 2.4 us per kernel; per-chunk maxima in
   // the fast path 1.6 us: three waves share a SIMD, every VALU instruction here is 12 cycles of it.)
-  constexpr int XB = NIT % 8 == 0 ? 8 : 6;            // float4 in flight per thread and batch (NIT = 8, 12 or 6)
+  constexpr int XB = NIT % 8 == 0 ? 8 : (NIT % 6 == 0 ? 6 : 4);   // float4 in flight per thread and batch (NIT = 8, 12, 6 or 4)
   static_assert(NIT % XB == 0, "whole batches");
   __shared__ __attribute__((aligned(16))) float s_rmax[ROWS][4];
   __shared__ float s_rs[ROWS];
@@ -1225,21 +1226,22 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
   }
 }
 
-template <int NCG, int KS, int EPI, int LN>
+template <int NCG, int KS, int EPI, int LN, int RGB = 2>
 static hipError_t dec_gemm_s_launch(const void* Ws, float unscale, const float* X, int N, int Nout, int K, const float* bias, float* out,
                                     const float* cvec, float eps, float* ws, unsigned* cnt, hipStream_t s) {
-  const dim3 grid(Nout / (16 * NCG), KS, ceil_div(N, 32));
+  const dim3 grid(Nout / (16 * NCG), KS, ceil_div(N, 16 * RGB));
   if (K != KS * 768 || Nout % (16 * NCG) != 0 || N < 1 || N > DEC_MAX_PREFIXES || Ws == nullptr) return hipErrorInvalidValue;
-  if (KS > 1 && ((int)(grid.x * grid.z) > DEC_MAX_COLGROUPS || (size_t)grid.x * grid.z * KS * NCG * 2 * 256 > DEC_SPLITK_WS_FLOATS || !ws || !cnt))
+  if (KS > 1 && ((int)(grid.x * grid.z) > DEC_MAX_COLGROUPS || (size_t)grid.x * grid.z * KS * NCG * RGB * 256 > DEC_SPLITK_WS_FLOATS || !ws || !cnt))
     return hipErrorInvalidValue;
-  constexpr int smem = 2 * 32 * (768 * 2 + 16);
+  constexpr int planes = 2 * 16 * RGB * (768 * 2 + 16), tiles = 4 * NCG * RGB * 1024;
+  constexpr int smem = planes > tiles ? planes : tiles;
   static DeviceOnce attr_once; bool& attr_set = attr_once.flag();
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_dec_gemm_s<NCG, KS, EPI, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)k_dec_gemm_s<NCG, KS, EPI, LN, RGB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_dec_gemm_s<NCG, KS, EPI, LN>), grid, dim3(256 * NCG), smem, s, (const u32x4_t*)Ws, X, N, Nout, K, bias, out, cvec, eps,
+  hipLaunchKernelGGL((k_dec_gemm_s<NCG, KS, EPI, LN, RGB>), grid, dim3(256 * NCG), smem, s, (const u32x4_t*)Ws, X, N, Nout, K, bias, out, cvec, eps,
                      unscale, ws, cnt);
   return hipGetLastError();
 }

@@ -203,6 +203,18 @@ int main(int argc, char** argv) {
       TS("fc", 2, 1, DE_GELU, 1, s_fc, x, 4 * E, E, hid, cvec);
       TS("fc2", 2, 4, DE_RESID, 0, s_fc2, hid, E, 4 * E, x, nullptr);
       TS("fc2", 3, 4, DE_RESID, 0, s_fc2, hid, E, 4 * E, x, nullptr);
+#define TS1(label, C, KSV, EPIV, LNV, WW, XX, NO, KK, OUT, CV) \
+      printf("s16 %-6s C%d KS%d %7.2f us  (%d wg)\n", label, C, KSV, time_chain([&] { dec_gemm_s_launch<C, KSV, EPIV, LNV, 1>(WW, un, XX, N, NO, KK, bias, OUT, CV, 1e-5f, ws, cnt, s); }), (NO / (16 * C)) * KSV * ((N + 15) / 16))
+      if (N <= 128) {
+        dec_gemm_rg<12, 1, DE_STORE, 1>(w_qkv, x, N, 3 * E, E, bias, ref, nullptr, cvec, 1e-5f, nullptr, nullptr, s);
+        CK((dec_gemm_s_launch<3, 1, DE_STORE, 1, 1>(s_qkv, un, x, N, 3 * E, E, bias, got, cvec, 1e-5f, ws, cnt, s))); cmp("s16 qkv C3", 3 * E);
+        TS1("qkv", 3, 1, DE_STORE, 1, s_qkv, x, 3 * E, E, qkv, cvec);
+        TS1("qkv", 2, 1, DE_STORE, 1, s_qkv, x, 3 * E, E, qkv, cvec);
+        TS1("fc", 3, 1, DE_GELU, 1, s_fc, x, 4 * E, E, hid, cvec);
+        TS1("fc", 2, 1, DE_GELU, 1, s_fc, x, 4 * E, E, hid, cvec);
+        TS1("fc2", 3, 4, DE_RESID, 0, s_fc2, hid, E, 4 * E, x, nullptr);
+        TS1("proj", 1, 1, DE_RESID, 0, s_proj, att, E, E, x, nullptr);
+      }
       TS("qkv", 4, 1, DE_STORE, 1, s_qkv, x, 3 * E, E, qkv, cvec);
       TS("fc", 4, 1, DE_GELU, 1, s_fc, x, 4 * E, E, hid, cvec);
       TS("fc2", 4, 4, DE_RESID, 0, s_fc2, hid, E, 4 * E, x, nullptr);
