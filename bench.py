@@ -132,6 +132,129 @@ def cpu_baseline():
                                              % ", ".join("%.1f" % t for t in t_c1)}}
 
 
+def other_configs(device_index: int):
+    """Per-GPU shards of BASELINE configs 3, 4 and 5 on the HIP path (rank 0, N = 1; ~40 s): one record each with the synchronous
+    forward (the reference's call pattern: median / p95 over timed calls), the pipelined figure where a pipeline exists, the stage
+    breakdown from HIP-event brackets and the ViT GEMM / attention rates against the MFMA peak.  `value` stays config 2.
+    c3: eval_trace_captioning.py:264-330 at 518^2 with 16 regions per image as boxes; c4: eval_densecap.py:437-450 (CapDec head:
+    no bank); c5: configs/mlp.viecap.k.yaml:1-31 with a ViT-L/14 backbone (synthetic GPT-2-base language model, 64 greedy steps)."""
+    import numpy as np
+    import golden_cases as gc
+    from patchioner_amd import Patchioner, viecap as V, weights as W
+    from patchioner_amd.pipeline import RegionCaptionPipeline, BoxRegions
+    dev = "cuda:%d" % device_index
+
+    def measure(m, call, n_capt, n_img, flops_img, attn_flops_img, timed=12, warm=3, pipe_factory=None, pipe_batches=24):
+        for _ in range(warm):
+            call()
+        torch.cuda.synchronize()
+        ms = []
+        for _ in range(timed):
+            t0 = time.perf_counter()
+            call()                                   # returns python strings: the forward has completed
+            ms.append((time.perf_counter() - t0) * 1e3)
+        st = _stats(ms)
+        m.engine.profile_enable(True)
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        prof = m.engine.profile_read()
+        m.engine.profile_enable(False)
+        stages = {k: {"ms_per_forward": v["ms"] / 3, "launches_per_forward": v["launches"] / 3,
+                      "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] and v["ms"] > 0 else None}
+                  for k, v in prof.items() if v["launches"]}
+        g, a = prof["vit_gemm"], prof.get("vit_attention", {"ms": 0.0, "flops": 0.0, "launches": 0})
+        rec = {"forward_sync": {"captions_per_s": n_capt * 1e3 / st["median"], "ms_per_forward": st, "ms_per_image": st["median"] / n_img},
+               "stages": stages,
+               "vit_gemm": {"tflops": g["flops"] / (g["ms"] * 1e-3) / 1e12, "frac": g["flops"] / (g["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                            "avg_launch_us": g["ms"] * 1e3 / max(g["launches"], 1), "gflop_per_image": flops_img / 1e9,
+                            "bracket": "HIP events on the launch stream, one synchronous forward at a time"},
+               "vit_attention": {"tflops": a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else None,
+                                 "avg_launch_us": a["ms"] * 1e3 / max(a["launches"], 1), "gflop_per_image": attn_flops_img / 1e9}}
+        if pipe_factory is not None:
+            pipe, feed = pipe_factory()
+            list(pipe.run(feed() for _ in range(4)))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in pipe.run(feed() for _ in range(pipe_batches)):
+                pass
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / pipe_batches
+            rec["pipelined"] = {"captions_per_s": n_capt / dt, "ms_per_batch": dt * 1e3, "api": "RegionCaptionPipeline.run (stage 1 of the next "
+                                "batch under the decode of this one; outputs identical to forward())", "batches": pipe_batches}
+            pipe.close()
+        return rec
+
+    out = {}
+    g = torch.Generator(device="cuda").manual_seed(6)
+    bank = torch.empty(BANK_ROWS, 768, device="cuda", dtype=torch.float32)
+    for s in range(0, BANK_ROWS, 65536):
+        e = min(BANK_ROWS, s + 65536)
+        bank[s:e] = torch.randn(e - s, 768, device="cuda", generator=g)
+    # ---- config 3: talk2dino_decap, 518^2 (T = 1374), batch 8, 16 gaussian boxes per image, full bank
+    B, NB, crop = 8, 16, 518
+    m = Patchioner.from_config({"decap_weights": W.synth_decap(3), "prefix_size": 768, "linear_talk2dino": False, "support_memory_size": BANK_ROWS,
+                                "dino_model": "dinov2_vitb14_reg", "normalize": True, "resize_dim": crop, "crop_dim": crop,
+                                "dino_weights": W.synth_dinov2(1), "memory_bank": bank, "max_batch": B, "max_prefixes": 256}, device=dev)
+    del bank
+    imgs = W.synth_images(5, B, crop).cuda()
+    rng = np.random.RandomState(4)
+    boxes = torch.tensor(np.concatenate([rng.randint(0, 30, size=(B, NB, 2)) * 14.0, rng.randint(1, 8, size=(B, NB, 2)) * 14.0], -1), dtype=torch.float32)
+    kw = dict(get_cls_capt=False, gaussian_avg=True, gaussian_bbox_variance=1.0)
+    T, D = 1374, 768
+    out["c3"] = measure(m, lambda: m(imgs, bboxes=boxes.clone(), **kw), B * NB, B,
+                        2.0 * 1369 * 588 * D + 12 * T * 14.156e6 * (D / 768.0) ** 2, 12 * 4.0 * T * T * D,
+                        pipe_factory=lambda: (RegionCaptionPipeline(m, group_batches=1, decode_clones=2),
+                                              lambda: (imgs, BoxRegions(boxes.clone(), gaussian_avg=True, gaussian_bbox_variance=1.0))))
+    out["c3"]["workload"] = ("config 3 at full size: talk2dino_decap, ViT-B/14-reg 518^2 (37 x 37 patches, T = 1374), batch 8, 16 gaussian-weighted "
+                             "boxes per image = 128 captions per forward, bank 591753 x 768, 30-step greedy decode")
+    m.engine.close()
+    del m, imgs
+    torch.cuda.empty_cache()
+    # ---- config 4, one GPU's shard of the 64-image batch: CapDec head (no bank), 8 images x 8 dense boxes
+    B, NB, crop = 8, 8, 224
+    m = Patchioner.from_config({"decap_weights": W.synth_decap(3), "dino_weights": W.synth_dinov2(1), "memory_bank": None, "prefix_size": 768,
+                                "linear_talk2dino": False, "support_memory_size": 0, "dino_model": "dinov2_vitb14_reg", "normalize": True,
+                                "resize_dim": crop, "crop_dim": crop, "max_batch": B, "max_prefixes": 64}, device=dev)
+    imgs = W.synth_images(4, B, crop).cuda()
+    rng = np.random.RandomState(4)
+    b = np.concatenate([rng.randint(0, 12, size=(B, NB, 2)) * 14.0, rng.randint(1, 9, size=(B, NB, 2)) * 14.0], -1).astype(np.float32)
+    b[:, -1] = [0.0, 0.0, 1.0, 1.0]                      # the dense-captioning driver's padding box (eval_densecap.py:332-333)
+    boxes4 = torch.tensor(b)
+    kw4 = dict(get_cls_capt=False, gaussian_avg=True, gaussian_bbox_variance=0.5)
+    T = 261
+    out["c4_shard"] = measure(m, lambda: m(imgs, bboxes=boxes4.clone(), **kw4), B * NB, B,
+                              2.0 * 256 * 588 * D + 12 * T * 14.156e6, 12 * 4.0 * T * T * D,
+                              pipe_factory=lambda: (RegionCaptionPipeline(m, group_batches=2, decode_clones=2),
+                                                    lambda: (imgs, BoxRegions(boxes4.clone(), gaussian_avg=True, gaussian_bbox_variance=0.5))))
+    out["c4_shard"]["workload"] = ("config 4, the per-GPU shard (64 images over 8 GPUs): talk2dino_capdec (no bank, raw region features into the "
+                                   "decoder), ViT-B/14-reg 224^2, 8 images x 8 dense boxes = 64 captions per forward")
+    m.engine.close()
+    del m, imgs
+    torch.cuda.empty_cache()
+    # ---- config 5, the per-GPU shard (128 images over 8 GPUs): ViT-L/14-reg at depth 24, fp16, attention-weighted traces, ViECap head
+    B, crop, D = 16, 224, 1024
+    vocab, merges = W.synth_bpe(0)
+    tok = V.ByteLevelBPE(vocab, merges)
+    ents = list(W.SYNTH_ENTITIES)
+    vc = dict(clip_hidden_size=D, weights=W.synth_viecap(311, clip_hidden_size=D, n_layer=12, tok_vocab=len(vocab)), tokenizer=tok,
+              entities_text=ents, texts_embeddings=W.synth_entity_embeddings(312, len(ents), D), temperature=gc.VIECAP["temperature"],
+              top_k=gc.VIECAP["top_k"], threshold=gc.VIECAP["threshold"], using_hard_prompt=True, soft_prompt_first=True, using_greedy_search=True)
+    m = Patchioner.from_config({"decap_weights": None, "prefix_size": 768, "linear_talk2dino": False, "support_memory_size": 0,
+                                "dino_model": "dinov2_vitl14_reg", "normalize": False, "resize_dim": crop, "crop_dim": crop,
+                                "dino_weights": W.synth_dinov2(93, "dinov2_vitl14_reg"), "max_batch": B, "max_prefixes": 16, "viecap": vc,
+                                "vit_dtype": "fp16"}, device=dev)
+    imgs = W.synth_images(8, B, crop).cuda()
+    traces = [gc.block_trace(i % 13, (5 * i) % 13) for i in range(B)]
+    out["c5_shard"] = measure(m, lambda: m(imgs, get_cls_capt=False, traces=traces, use_attention_tracing=True), B, B,
+                              2.0 * 256 * 588 * D + 24 * T * 14.156e6 * (D / 768.0) ** 2, 24 * 4.0 * T * T * D)
+    out["c5_shard"]["workload"] = ("config 5, the per-GPU shard (128 images over 8 GPUs): ViT-L/14-reg 224^2 at depth 24 (D = 1024, 16 heads; 164.7 GFLOP "
+                                   "per image), fp16 operands, batch 16, attention-weighted trace regions, ViECap head (hard + soft prompt, synthetic "
+                                   "GPT-2-base, 64 greedy steps)")
+    m.engine.close()
+    return out
+
+
 def self_launch(n_gpus: int) -> int:
     """``python bench.py --gpus N`` without a torch.distributed.run environment: start the N ranks as FRESH child processes
     (one per GPU) and return their exit code.  Nothing in this parent has touched the GPU (importing torch does not), and
@@ -192,6 +315,7 @@ def main():
                     help="timed steps (16 groups of 8 batches by default: the pipeline's fill and drain, about 5 ms, are inside the timed region)")
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the records of BASELINE configs 3 / 4 / 5 (`configs` in the line; ~40 s)")
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("PIO_BENCH_IN_FLIGHT", "8")),
                     help="batches per decode group (mode=group: stage 1 runs per bs-16 batch, ONE greedy decode serves "
                          "this many batches, <= 8 = 128 prefixes) or forwards in flight (mode=streams); 1 = the "
@@ -470,6 +594,10 @@ def main():
             "stages": stages,
             "preprocess": prep,
         }
+        if not args.no_configs and world == 1:           # BASELINE configs 3 / 4 / 5, per-GPU shards (N = 1 only: keeps an N-rank run inside the driver's budget)
+            if pipe is not None:
+                pipe.close()
+            line["configs"] = other_configs(local)
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -35,8 +35,14 @@ MARGIN_BOUND = 1e-3
 # because step (1) already ties G to the oracle on P): a caption may depart only at a near-tie of the REFERENCE (top-2 margin <=
 # MARGIN_BOUND, fixed), the HIP prefix has to sit within PREFIX_REL_BOUND of the fp32 path's (relative L2 per row; a wrong ViT /
 # projection fails here however the captions fall), and at most DEPART_FRACTION of a call set's captions may depart at all.
-PREFIX_REL_BOUND = {"fp16": 2e-2, "bf16": 2e-1}
+PREFIX_REL_BOUND = {"fp16": 2e-2, "bf16": 8e-2}
 DEPART_FRACTION = 0.03
+# bf16 operands carry 8 significant bits where fp16 carries 11: the backbone's rounding error, the prefix error behind the T = 0.01
+# projection and the logit shifts all scale by 8, so the bf16 ceilings are the fp16 ones x 8 for the margin, x 4 for the prefix
+# (fp16 measured 4.1e-3 under its 2e-2) and a larger share of captions may sit at a (wider) near-tie.  Used by the one bf16
+# end-to-end test (test_gpu_parity.py::test_e2e_full_depth_bf16_backbone_ledger); every other test runs the fp16 default.
+MARGIN_BOUND_BY = {"fp16": MARGIN_BOUND, "bf16": 8e-3}
+DEPART_FRACTION_BY = {"fp16": DEPART_FRACTION, "bf16": 0.10}
 REPORT = []          # one record per assert_ids_explained call; conftest.pytest_terminal_summary prints and saves them
 REPORT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_parity_report.json")
 
@@ -74,8 +80,8 @@ def assert_ids_explained(dec_oracle, gpu_log, ref_ids, label="", ref_prefixes=No
             top2 = l_ref.topk(2).values
             m, moved = float(top2[0] - top2[1]), float((l_hip - l_ref).abs().max())
             worst, worst_moved = max(worst, m), max(worst_moved, moved)
-            assert m <= MARGIN_BOUND, ("%s: caption %d departs from the reference at step %d where the reference's top-2 margin "
-                                       "is %.3e (> %.1e): not a near-tie" % (label, r, t, m, MARGIN_BOUND))
+            assert m <= MARGIN_BOUND_BY[operands], ("%s: caption %d departs from the reference at step %d where the reference's top-2 margin "
+                                                    "is %.3e (> %.1e): not a near-tie" % (label, r, t, m, MARGIN_BOUND_BY[operands]))
             assert m <= 2.0 * moved, ("%s: caption %d departs from the reference at step %d where the reference's top-2 margin is "
                                       "%.3e but the prefix perturbation moves the logits by at most %.3e: not explained"
                                       % (label, r, t, m, moved))
@@ -85,7 +91,7 @@ def assert_ids_explained(dec_oracle, gpu_log, ref_ids, label="", ref_prefixes=No
             assert m <= MARGIN_BOUND, ("%s: caption %d departs from the reference at step %d where the top-2 margin is %.3e "
                                        "(> %.2e): not a near-tie" % (label, r, t, m, MARGIN_BOUND))
     total = int(keep.sum())
-    assert departed <= max(1, math.ceil(DEPART_FRACTION * total)), "%s: %d of %d captions depart from the reference" % (label, departed, total)
+    assert departed <= max(1, math.ceil(DEPART_FRACTION_BY[operands] * total)), "%s: %d of %d captions depart from the reference" % (label, departed, total)
     REPORT.append(dict(test=os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], label=label, identical=total - departed, total=total,
                        departures=departed, worst_margin_at_departure=worst, bound="derived+fixed" if RPk is not None else "fixed 1e-3",
                        max_logit_shift_at_departure=worst_moved, max_prefix_rel_err=prefix_rel, operands=operands))

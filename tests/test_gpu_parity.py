@@ -557,6 +557,38 @@ def test_e2e_full_depth_ids_vs_oracle(O, with_bank):
     assert total == 4 * 3 + boxes.shape[0] * boxes.shape[1]
 
 
+def test_e2e_full_depth_bf16_backbone_ledger(O):
+    """north_star says "MFMA bf16/fp16 GEMMs": the SAME whole path with ``vit_dtype="bf16"`` (bf16 operands in every ViT GEMM and in the
+    attention, fp32 accumulation / residual / LayerNorm as always), depth 12, the inputs of test_e2e_full_depth_ids_vs_oracle with the
+    bank.  The decoder stays bit-exact on the HIP path's own prefixes (clause 1); through the backbone a caption may leave the fp32
+    reference only at a near-tie that the measured logit shift explains, under the bf16 ceilings of parity_helpers (8 significant bits
+    instead of 11: margin 8e-3, prefix 8e-2 relative L2, at most 10 % of a set).  The ledger line (identical / departed, worst margin,
+    largest prefix error) is printed by conftest and quoted in README: fp16 is the default because it departs less."""
+    from patchioner_amd import Patchioner
+    from patchioner_amd.tokenizer import ClipDetokenizer
+    vit_sd, dec_sd = W.synth_dinov2(101), W.synth_decap(103)
+    bank = W.synth_bank(105, 4096)
+    cfg = {"decap_weights": dec_sd, "prefix_size": 768, "linear_talk2dino": False, "support_memory_size": 4096,
+           "dino_model": "dinov2_vitb14_reg", "normalize": True, "resize_dim": 224, "crop_dim": 224, "dino_weights": vit_sd,
+           "memory_bank": bank, "max_batch": 4, "vit_dtype": "bf16"}
+    m = Patchioner.from_config(cfg, device="cuda")
+    dec = O.DeCapOracle(dec_sd)
+    orc = O.PatchionerOracle(O.DinoV2Oracle(vit_sd, num_heads=12), dec, bank, ClipDetokenizer().decode, crop_dim=224)
+    imgs = W.synth_images(107, 4, 224)
+    traces = [gc.block_trace(2, 3), gc.block_trace(9, 9), gc.block_trace(0, 12), gc.block_trace(6, 1)]
+    boxes = gc.e2e_boxes()
+    kw = dict(get_cls_capt=True, get_avg_self_attn_capt=True, traces=traces, use_attention_tracing=True, gaussian_avg=True,
+              gaussian_bbox_variance=1.0)
+    m.call_log, orc.call_log, orc.prefix_log = [], [], []
+    got = m(imgs.cuda(), bboxes=boxes.clone(), **kw)
+    want = orc.forward(imgs.clone(), bboxes=boxes.clone(), **kw)
+    assert set(got) == set(want) and all(len(got[k]) == len(want[k]) for k in want)
+    same, total = assert_ids_explained(dec, m.call_log, orc.call_log, "depth-12 e2e, bf16 backbone", ref_prefixes=orc.prefix_log,
+                                       operands="bf16")
+    assert total == 4 * 3 + boxes.shape[0] * boxes.shape[1]
+    m.engine.close()
+
+
 def test_api_surface_and_mutation_quirks():
     m = _make_model(True)
     assert m.patch_size == 14 and m.crop_dim == 224 and m.resize_dim == 224 and m.num_tokens == 261

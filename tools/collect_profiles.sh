@@ -16,14 +16,14 @@ R=$(pwd)
 out=$R/gpurun_out/profiles_$round
 mkdir -p $out/sync $out/pipe $out/pmc_f $out/pmc_w $out/pmc_pf $out/pmc_pw $out/pmc_sq
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/sync -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --in-flight 1 > $out/sync/bench.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/pipe -- python3 $R/bench.py --no-cpu-baseline > $out/pipe/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/sync -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs --in-flight 1 > $out/sync/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/pipe -- python3 $R/bench.py --no-cpu-baseline --no-configs > $out/pipe/bench.log 2>&1
 export PIO_BENCH_STAT_GROUPS=4 PIO_BENCH_SYNC_STEPS=4      # counter passes serialise every dispatch: keep the statistics regions short
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_f -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --in-flight 1 > $out/pmc_f/run.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_w -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --in-flight 1 > $out/pmc_w/run.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_pf -- python3 $R/bench.py --steps 8 --warmup 8 --no-cpu-baseline > $out/pmc_pf/run.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_pw -- python3 $R/bench.py --steps 8 --warmup 8 --no-cpu-baseline > $out/pmc_pw/run.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $out/pmc_sq -- python3 $R/bench.py --steps 8 --warmup 8 --no-cpu-baseline > $out/pmc_sq/run.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_f -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-configs --in-flight 1 > $out/pmc_f/run.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_w -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-configs --in-flight 1 > $out/pmc_w/run.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_pf -- python3 $R/bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-configs > $out/pmc_pf/run.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_pw -- python3 $R/bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-configs > $out/pmc_pw/run.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $out/pmc_sq -- python3 $R/bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-configs > $out/pmc_sq/run.log 2>&1
 unset PIO_BENCH_STAT_GROUPS PIO_BENCH_SYNC_STEPS
 cd $R
 python3 tools/pmc_counters.py $(find $out/pmc_sq -name "*counter_collection.csv" | head -1) pio profiles/${round}_sq_counters.json > $out/pmc_sq/summary.txt

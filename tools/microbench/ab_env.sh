@@ -3,7 +3,7 @@
 for spec in "$@"; do
   set -- $spec; v=$1; shift
   if [ "$v" = default ]; then unset PIO_LIB_PATH; else export PIO_LIB_PATH=$PWD/tools/microbench/bin/libpio_$v.so; fi
-  env "$@" timeout -k 10 300 python bench.py --steps ${AB_STEPS:-40} --warmup 8 --no-cpu-baseline > gpurun_out/ab.json 2> gpurun_out/ab.err || { tail -5 gpurun_out/ab.err; exit 1; }
+  env "$@" timeout -k 10 300 python bench.py --steps ${AB_STEPS:-40} --warmup 8 --no-cpu-baseline --no-configs > gpurun_out/ab.json 2> gpurun_out/ab.err || { tail -5 gpurun_out/ab.err; exit 1; }
   python - "$spec" <<'PY'
 import json, sys
 d = json.loads(open("gpurun_out/ab.json").read().strip().splitlines()[-1])

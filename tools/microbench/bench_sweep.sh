@@ -9,7 +9,7 @@ run() {   # label, env assignments..., -- bench args...
   local envs=()
   while [ "$1" != "--" ]; do envs+=("$1"); shift; done
   shift
-  env "${envs[@]}" timeout -k 10 240 python3 bench.py --no-cpu-baseline "$@" 2> gpurun_out/sweep_err.log | tail -1 | python3 -c "
+  env "${envs[@]}" timeout -k 10 240 python3 bench.py --no-cpu-baseline --no-configs "$@" 2> gpurun_out/sweep_err.log | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('%-34s value %7.0f  group median %.2f ms p95 %.2f  gemm %.1f us frac %.3f' % ('$label', d['value'], d['pipelined_groups']['ms_per_group']['median'], d['pipelined_groups']['ms_per_group']['p95'], d['roofline']['avg_launch_us'], d['roofline']['frac']))" >> gpurun_out/sweep.log || return 1

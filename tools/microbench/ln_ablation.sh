@@ -6,7 +6,7 @@ export PIO_LIB_PATH=$PWD/tools/microbench/bin/libpio_abl.so
 for r in 1 2; do
 for v in with_ln skip_ln; do
   if [ $v = skip_ln ]; then export PIO_ABL_SKIP_LN=1; else unset PIO_ABL_SKIP_LN; fi
-  timeout -k 10 300 python bench.py --steps 128 --warmup 16 --no-cpu-baseline > gpurun_out/ab.json 2> gpurun_out/ab.err || { tail -5 gpurun_out/ab.err; exit 1; }
+  timeout -k 10 300 python bench.py --steps 128 --warmup 16 --no-cpu-baseline --no-configs > gpurun_out/ab.json 2> gpurun_out/ab.err || { tail -5 gpurun_out/ab.err; exit 1; }
   python - "$v" <<'PY'
 import json, sys
 d = json.loads(open("gpurun_out/ab.json").read().strip().splitlines()[-1])
