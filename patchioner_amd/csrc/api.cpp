@@ -60,7 +60,8 @@ struct HostTensor {
 
 struct VitLayerDev {
   float *n1w, *n1b, *qkvb, *projb, *ls1, *n2w, *n2b, *fc1b, *fc2b, *ls2;
-  void *qkvw, *projw, *fc1w, *fc2w;
+  float *projb_ls, *fc2b_ls;     // ls1 * proj.bias, ls2 * fc2.bias: the MFMA path's residual GEMMs take LayerScale folded into their operands
+  void *qkvw, *projw, *fc1w, *fc2w;     // projw / fc2w: rows scaled by ls1 / ls2 before the conversion to the operand type (kernels.h, EPI_RESIDUAL)
 };
 
 struct GraphKey {
@@ -299,7 +300,26 @@ int finalize_vit(pio_context* c) {
                {"mlp.fc1.weight", 4 * D, D, &L.fc1w}, {"mlp.fc2.weight", D, 4 * D, &L.fc2w}};
     for (auto& w : ws) {
       if ((rc = need(c, pre + w.key, {w.rows, w.cols}, &t))) return rc;
-      if ((rc = upload_op(c, t->data.data(), w.rows, w.cols, w.cols, w.dst))) return rc;
+      const char* lsk = w.dst == &L.projw ? "ls1.gamma" : (w.dst == &L.fc2w ? "ls2.gamma" : nullptr);
+      if (lsk == nullptr || clip) {
+        if ((rc = upload_op(c, t->data.data(), w.rows, w.cols, w.cols, w.dst))) return rc;
+        if (lsk != nullptr) (w.dst == &L.projw ? L.projb_ls : L.fc2b_ls) = (w.dst == &L.projw ? L.projb : L.fc2b);     // CLIP: no LayerScale
+        continue;
+      }
+      // proj / fc2: x += ls * (A W^T + b) = A (ls W)^T + ls b -- LayerScale folded into the operands in fp32, rounded to the operand
+      // type ONCE (the same relative rounding as W itself: the product's error is unchanged), so that the residual GEMM's sum can take
+      // the old x in as one of its terms (kernels.h, EPI_RESIDUAL); the exact-fp32 parity mode keeps W, b and ls apart (vit_fp32.hip)
+      const HostTensor *tg, *tb;
+      if ((rc = need(c, pre + lsk, {w.rows}, &tg))) return rc;
+      if ((rc = need(c, pre + (w.dst == &L.projw ? "attn.proj.bias" : "mlp.fc2.bias"), {w.rows}, &tb))) return rc;
+      std::vector<float> wf((size_t)w.rows * w.cols), bf(w.rows);
+      for (int64_t r = 0; r < w.rows; ++r) {
+        const float gmm = tg->data[r];
+        bf[r] = gmm * tb->data[r];
+        for (int64_t k = 0; k < w.cols; ++k) wf[(size_t)r * w.cols + k] = gmm * t->data[(size_t)r * w.cols + k];
+      }
+      if ((rc = upload_op(c, wf.data(), w.rows, w.cols, w.cols, w.dst))) return rc;
+      if ((rc = upload_f32(c, bf.data(), w.rows, w.dst == &L.projw ? &L.projb_ls : &L.fc2b_ls))) return rc;
     }
     if (c->vit_f32) {
       if ((int)c->vl32.size() != depth) c->vl32.resize(depth);
@@ -947,7 +967,7 @@ static int run_vit_block(pio_handle c, const VitLayerDev& L, int B, const GemmAr
   PROF(c, PIO_PROF_VIT_ATTN, 4.0 * B * (double)c->T * c->T * D, 0, s, launch_vit_attention(c->op, at, s));
   {
     GemmArgs a = g;
-    a.A = c->ao; a.lda = D; a.W = L.projw; a.bias = L.projb; a.ls = L.ls1; a.M = M; a.N = D; a.K = D;
+    a.A = c->ao; a.lda = D; a.W = L.projw; a.bias = L.projb_ls; a.M = M; a.N = D; a.K = D;
     a.pf = L.fc1w; a.pf_bytes = 4 * D * D * 2;
     PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * D * D, 0, s, launch_vit_gemm(c->op, EPI_RESIDUAL, a, s));
   }
@@ -963,7 +983,7 @@ static int run_vit_block(pio_handle c, const VitLayerDev& L, int B, const GemmAr
   }
   {
     GemmArgs a = g;
-    a.A = c->hbuf; a.lda = 4 * D; a.W = L.fc2w; a.bias = L.fc2b; a.ls = L.ls2; a.M = M; a.N = D; a.K = 4 * D;
+    a.A = c->hbuf; a.lda = 4 * D; a.W = L.fc2w; a.bias = L.fc2b_ls; a.M = M; a.N = D; a.K = 4 * D;
     if (next != nullptr) { a.pf = next->qkvw; a.pf_bytes = 3 * D * D * 2; }
     PROF(c, PIO_PROF_VIT_GEMM, 2.0 * Malg * 4.0 * D * D, 0, s, launch_vit_gemm(c->op, EPI_RESIDUAL, a, s));
   }

@@ -14,7 +14,7 @@ enum OperandType { OP_F16 = 0, OP_BF16 = 1 };
 enum GemmEpilogue {
   EPI_PATCH_EMBED = 0,  // x[b*Tp + G + p][n]  = acc + bias[n] + pos[(1+p)][n]          (fp32)
   EPI_QKV = 1,          // q/k [b][h][Tk][64], vT [b][h][64][Tk] (operand type) (+ fp32 qkv_last [B][T][3D])
-  EPI_RESIDUAL = 2,     // x[m][n] += ls[n] * (acc + bias[n])                            (fp32)
+  EPI_RESIDUAL = 2,     // x[m][n] += acc + bias[n], LayerScale folded into W and bias at load (fp32; the order of the sum: resid_join_ktile)
   EPI_GELU = 3          // out16[m][n] = gelu_erf(acc + bias[n])                         (operand type)
 };
 
@@ -29,7 +29,6 @@ struct GemmArgs {
   // epilogue operands
   float* x;            // residual stream [B*Tp][D] fp32 (PATCH_EMBED, RESIDUAL)
   const float* pos;    // interpolated position table [1+n2][D] (PATCH_EMBED)
-  const float* ls;     // LayerScale gamma [N] (RESIDUAL)
   void* out16;         // GELU output [M][N]
   void* q; void* k; void* vT;   // QKV outputs
   float* qkv_last;     // optional fp32 capture [B][T][3D]
@@ -55,11 +54,27 @@ __device__ __forceinline__ void gemm_warm_next(const GemmArgs& g, int e, int ne,
   asm volatile("" :: "v"(acc));
 }
 
+// EPI_RESIDUAL, the arithmetic EVERY GEMM kernel follows (one definition, so that an element of x never depends on the kernel or the
+// launch size that produced it).  LayerScale is folded into the operands at load (api.cpp: W' = op(ls[n] W[n][k]), b' = ls[n] b[n]), and
+//     x_new[m][n] = ( sum over k ascending in MFMA steps of 16, from 0, with the OLD x[m][n] joining the sum after K-tile J ) + b'[n]
+// where a K-tile is 64 consecutive k and J depends on where the element sits in the 256 x 256 grid: unit u = 2 q + rt with
+// q = the quadrant's phase (I, J) = (0,0) (0,1) (1,1) (1,0) -> 0 1 2 3 for I = (m % 256) / 128, J = (n % 256) / 128 and rt = (m % 64) / 32;
+// J(u) = min({2, 3, 4, 5, 6, 7, 7, 8}[u], K / 64 - 1).  Why x joins in the MIDDLE of the sum: the persistent kernel (vit_gemm_roll.hip)
+// fetches x one unit per K-tile through 32 KiB of LDS while the multiplies run, so that the fp32 read of the residual stream -- half of
+// the epilogue that used to be exposed -- costs no time; at the end (or the start) of the sum all of a tile's x would be needed at once.
+__host__ __device__ constexpr int resid_unit(int m, int n) {
+  return 2 * (((m & 255) >> 7) == 0 ? ((n & 255) >> 7) : 3 - ((n & 255) >> 7)) + ((m & 63) >> 5);
+}
+__host__ __device__ constexpr int resid_join_ktile(int u, int nk) {
+  return (u < 6 ? u + 2 : u + 1) < nk - 1 ? (u < 6 ? u + 2 : u + 1) : nk - 1;
+}
+
 hipError_t launch_vit_gemm(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
 // 256 x 256 tiles, 8 waves (vit_gemm256.hip): same arithmetic per output element; launch_vit_gemm dispatches to it
 bool vit_gemm256_fits(GemmEpilogue epi, const GemmArgs& a);
 hipError_t launch_vit_gemm256(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
-// persistent 256 x 256 workgroups with a rolling epilogue (vit_gemm_roll.hip): qkv without capture and fc1 at many tiles per CU
+// persistent 256 x 256 workgroups with a rolling epilogue (vit_gemm_roll.hip): qkv without capture and fc1 at many tiles per CU, proj / fc2
+// (EPI_RESIDUAL) from one tile per CU on
 bool vit_gemm_roll_fits(GemmEpilogue epi, const GemmArgs& a);
 hipError_t launch_vit_gemm_roll(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
 

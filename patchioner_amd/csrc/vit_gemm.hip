@@ -6,7 +6,7 @@
 // Replaces the stock ATen calls behind DINOv2's PatchEmbed conv, attn.qkv, attn.proj, mlp.fc1, mlp.fc2
 // (reached from P/src/model.py:783) and fuses what followed them in the reference: bias, position
 // embedding add, q/k/v head split (+ the fp32 capture the qkv forward hook takes,
-// P/src/dino_extraction.py:7-9), LayerScale + residual add, exact-erf GELU.
+// P/src/dino_extraction.py:7-9), LayerScale (folded into W and bias at load) + residual add, exact-erf GELU.
 //
 // This file: the dispatch (launch_vit_gemm) and k_vit_gemm, the 128-wide kernel that serves GEMMs with fewer than ~150
 // tiles of 256 x 256 (a synchronous 16-image forward's proj / fc2, small box-sequence batches); larger ones go to
@@ -112,6 +112,37 @@ __global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? PIO_GEMM_WIDE_OCC
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // EPI_RESIDUAL (kernels.h: resid_join_ktile): the old x of this wave's elements, loaded up front (32 registers per 32-row block: this
+  // kernel has them to spare) and added to the running sums after the K-tile the canonical order names.  A 32 x 32 block of a wave lies
+  // inside one unit of the 256-grid, so the K-tile is wave-uniform per block.
+  const int nk = g.K / BK;                  // even and >= 2 (checked by the launcher)
+  float xin[EPI == EPI_RESIDUAL ? MI : 1][2][16];
+  int xjoin[MI];
+  if constexpr (EPI == EPI_RESIDUAL) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int mb = m0 + wm * (BM / 2) + i * 32;
+      xjoin[i] = resid_join_ktile(resid_unit(mb, n0), nk);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + acc_row32(r, lane);
+          xin[i][j][r] = m < g.M ? g.x[(size_t)m * g.N + n0 + wn * 64 + j * 32 + r31] : 0.f;
+        }
+    }
+  }
+#define PIO_JOIN_X(kt)                                                                                 \
+  do {                                                                                                 \
+    if constexpr (EPI == EPI_RESIDUAL) {                                                               \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
+        if ((kt) == xjoin[i]) {                                                                        \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r) \
+            acc[i][j][r] += xin[i][j][r];                                                              \
+        }                                                                                              \
+    }                                                                                                  \
+  } while (0)
+
 #define PIO_ISSUE_TILE(kt, buf)                                                                        \
   do {                                                                                                 \
     if (PIO_ABL_NOGLOAD) break;                                                                        \
@@ -144,14 +175,20 @@ __global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? PIO_GEMM_WIDE_OCC
     }                                                                                \
   } while (0)
 
-  const int nk = g.K / BK;                  // even and >= 2 (checked by the launcher)
+  // An LDS-DMA tile has LANDED once the issuing wave's vmcnt has drained (and the barrier has passed, for the other waves' pieces).
+  // Spelled out: the compiler's own wait insertion treats the DMA as an LDS write that a later ds_read may alias and usually puts a
+  // vmcnt(0) in front of the barrier, but round 5 found it missing on the back edge of the two-buffer loop once the kernel also held
+  // ordinary global loads (the old x of EPI_RESIDUAL): tiles were multiplied before they had arrived.
+#define PIO_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
   if constexpr (NBUF == 1) {
     // one 32-KiB buffer, up to four workgroups per CU: a workgroup's own load and multiply phases alternate and
     // the CU overlaps them across its workgroups (the __syncthreads() after the issue waits vmcnt(0): landed).
     for (int kt = 0; kt < nk; ++kt) {
       PIO_ISSUE_TILE(kt, 0);
+      PIO_LANDED();
       __syncthreads();
       PIO_COMPUTE_TILE(0);
+      PIO_JOIN_X(kt);
       __syncthreads();
     }
   } else if constexpr (NBUF == 3) {
@@ -171,6 +208,7 @@ __global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? PIO_GEMM_WIDE_OCC
       __builtin_amdgcn_s_barrier();
       if (kt + 2 < nk) PIO_ISSUE_TILE(kt + 2, nxt);
       PIO_COMPUTE_TILE(cur);
+      PIO_JOIN_X(kt);
       cur = cur == 2 ? 0 : cur + 1;
       nxt = nxt == 2 ? 0 : nxt + 1;
     }
@@ -180,22 +218,32 @@ __global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? PIO_GEMM_WIDE_OCC
     // two buffers: tile kt+1 is in flight (LDS-DMA, no registers) while tile kt is multiplied; one barrier per tile
     PIO_ISSUE_TILE(0, 0);
     for (int kt = 0; kt < nk - 2; kt += 2) {
+      PIO_LANDED();
       __syncthreads();                       // tile kt landed; everyone is done reading buffer 1
       PIO_ISSUE_TILE(kt + 1, 1);
       PIO_COMPUTE_TILE(0);
+      PIO_JOIN_X(kt);
+      PIO_LANDED();
       __syncthreads();
       PIO_ISSUE_TILE(kt + 2, 0);
       PIO_COMPUTE_TILE(1);
+      PIO_JOIN_X(kt + 1);
     }
+    PIO_LANDED();
     __syncthreads();
     PIO_ISSUE_TILE(nk - 1, 1);
     PIO_COMPUTE_TILE(0);
+    PIO_JOIN_X(nk - 2);
+    PIO_LANDED();
     __syncthreads();
     PIO_COMPUTE_TILE(1);
+    PIO_JOIN_X(nk - 1);
     __syncthreads();                         // every wave is done reading the operand tiles
   }
 #undef PIO_ISSUE_TILE
 #undef PIO_COMPUTE_TILE
+#undef PIO_JOIN_X
+#undef PIO_LANDED
 
   // ---- epilogue: accumulators -> LDS [64][128] fp32 (one 32-row MFMA tile row of each wave per pass) ->
   //      row-major 16-B-per-lane global accesses.  Image row c holds tile row (c >> 5) * (BM / 2) + 32 * pass + (c & 31).
@@ -207,9 +255,7 @@ __global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? PIO_GEMM_WIDE_OCC
   const bool v_block = EPI == EPI_QKV && n0 >= 2 * g.D;      // block-uniform: D % 128 == 0
   const int c4 = (tid & 31) * 4, rbase = tid >> 5;
   const int n = n0 + c4;
-  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), l4 = b4;
-  b4 = *(const float4*)(g.bias + n);
-  if constexpr (EPI == EPI_RESIDUAL) l4 = *(const float4*)(g.ls + n);
+  const float4 b4 = *(const float4*)(g.bias + n);
   if (v_block) {
     // V is stored TRANSPOSED ([b][h][d][t]) and the accumulator already is: a lane holds one column d and, per
     // register group a = r >> 2, the 4 consecutive tokens 8 a + 4 h + (r & 3).  v_permlane32_swap pairs the two
@@ -282,11 +328,8 @@ __global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? PIO_GEMM_WIDE_OCC
         const int b = m / g.n2, p = m - b * g.n2;
         const float4 ps = *(const float4*)(g.pos + (size_t)(1 + p) * g.D + n);
         *(float4*)(g.x + (size_t)(b * g.Tp + g.G + p) * g.D + n) = make_float4(v.x + ps.x, v.y + ps.y, v.z + ps.z, v.w + ps.w);
-      } else if constexpr (EPI == EPI_RESIDUAL) {
-        float4* px = (float4*)(g.x + (size_t)m * g.N + n);
-        float4 xo = *px;
-        xo.x += l4.x * v.x; xo.y += l4.y * v.y; xo.z += l4.z * v.z; xo.w += l4.w * v.w;
-        *px = xo;
+      } else if constexpr (EPI == EPI_RESIDUAL) {      // the old x joined the sum in the main loop (PIO_JOIN_X)
+        *(float4*)(g.x + (size_t)m * g.N + n) = v;
       } else if constexpr (EPI == EPI_GELU) {
         if (g.act == 1) store_half4<T>((T*)g.out16 + (size_t)m * g.N + n, quick_gelu(v.x), quick_gelu(v.y), quick_gelu(v.z), quick_gelu(v.w));
         else store_half4<T>((T*)g.out16 + (size_t)m * g.N + n, gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
@@ -351,7 +394,10 @@ static hipError_t launch_typed(GemmEpilogue epi, const GemmArgs& a, hipStream_t 
       // 32 images and more per launch (the pipeline's shared ViT launches): 128-row tiles fill the chip on their own
       // (>= 1.5 workgroups per CU) and halve the W re-reads: 2.90 vs 3.21 ms per 32-image forward.  Same k order per
       // element, so the result does not depend on the tile height.
-      if (ceil_div(a.M, 128) * (a.N / BN) >= 384) return launch_one<T, EPI_RESIDUAL, 128, 2>(a, s);
+      {
+        static const int force_bm = [] { const char* e = getenv("PIO_GEMM_RES_BM"); return e ? atoi(e) : 0; }();   // diagnostic: 64 / 128
+        if (force_bm == 128 || (force_bm == 0 && ceil_div(a.M, 128) * (a.N / BN) >= 384)) return launch_one<T, EPI_RESIDUAL, 128, 2>(a, s);
+      }
       return launch_one<T, EPI_RESIDUAL, PIO_GEMM_BM_NARROW, PIO_GEMM_NBUF_NARROW>(a, s);
     case EPI_GELU:
       if constexpr (PIO_GEMM_BM_BIG != 0) { if (a.M >= PIO_GEMM_BIG_M) return launch_one<T, EPI_GELU, PIO_GEMM_BM_BIG == 0 ? 128 : PIO_GEMM_BM_BIG, PIO_GEMM_NBUF_BIG>(a, s); }
@@ -392,7 +438,19 @@ static int gemm_roll_min_tiles() {
   return v;
 }
 
+// proj / fc2: the rolling kernel from the tile count at which 256 x 256 tiles fill the chip (the 256 kernel's own threshold; it has no
+// residual epilogue any more).  PIO_GEMM_RRES_MIN_TILES overrides (0 = never: the 128-wide kernel everywhere).
+static int gemm_rres_min_tiles() {
+  static const int v = [] { const char* e = getenv("PIO_GEMM_RRES_MIN_TILES"); return e ? atoi(e) : 144; }();
+  return v;
+}
+
 hipError_t launch_vit_gemm(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
+  if (epi == EPI_RESIDUAL) {
+    if (gemm_rres_min_tiles() > 0 && a.M > 0 && a.N % 256 == 0 && ceil_div(a.M, 256) * (a.N / 256) >= gemm_rres_min_tiles() &&
+        vit_gemm_roll_fits(epi, a))
+      return launch_vit_gemm_roll(t, epi, a, s);
+  } else
   if (gemm_roll_min_tiles() > 0 && a.M > 0 && a.N % 256 == 0 && ceil_div(a.M, 256) * (a.N / 256) >= gemm_roll_min_tiles() &&
       vit_gemm_roll_fits(epi, a))
     return launch_vit_gemm_roll(t, epi, a, s);

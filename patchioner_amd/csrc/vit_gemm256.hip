@@ -84,6 +84,7 @@ template <typename T> struct Vec4h { typedef T type __attribute__((ext_vector_ty
 template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void k_vit_gemm256(const GemmArgs g) {
   using namespace g256;
+  static_assert(EPI != EPI_RESIDUAL, "proj / fc2 at 256 x 256 tiles: k_vit_gemm_roll (the old x joins the sum inside the main loop, kernels.h)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Vec8<T>::type frag_t;
   typedef typename Vec4h<T>::type half4_t;
@@ -347,14 +348,12 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm256(const GemmArgs g) {
 
   // ---- fp32 outputs (residual stream, patch embedding, the captured qkv): two passes of 128 rows through a
   //      [128][256] fp32 image (1-KiB rows, chunk index XORed with row & 7); a wave-instruction reads back one whole row
-  //      (row = wave-uniform: its bounds test and image split are scalar).  What the read-back combines with (the old
-  //      residual rows, the position rows) is loaded BEFORE the pass is staged, all 16 rows of the wave at once, and the
+  //      (row = wave-uniform: its bounds test and image split are scalar).  What the read-back combines with (the position
+  //      rows) is loaded BEFORE the pass is staged, all 16 rows of the wave at once, and the
   //      second pass's rows while the first pass is read back: one exposed memory latency per tile instead of eight.
   const int n = n0 + 4 * lane;
   const float4 b4 = *(const float4*)(g.bias + n);
-  float4 l4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (EPI == EPI_RESIDUAL) l4 = *(const float4*)(g.ls + n);
-  constexpr bool PRE = EPI == EPI_RESIDUAL || EPI == EPI_PATCH_EMBED;
+  constexpr bool PRE = EPI == EPI_PATCH_EMBED;
   float4 pre0[PRE ? 16 : 1], pre1[PRE ? 16 : 1];
 #define G256_PRELOAD(dst, i)                                                                            \
   do {                                                                                                  \
@@ -363,13 +362,9 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm256(const GemmArgs g) {
         const int rr = (i) * 128 + wid * 16 + it;                                                       \
         dst[it] = make_float4(0.f, 0.f, 0.f, 0.f);                                                      \
         if (m0 + rr < g.M) {                                                                            \
-          if constexpr (EPI == EPI_RESIDUAL) {                                                          \
-            dst[it] = *(const float4*)(g.x + (size_t)(m0 + rr) * g.N + n);                              \
-          } else {                                                                                      \
-            G256_SPLIT(rr, b, p);                                                                       \
-            (void)b;                                                                                    \
-            dst[it] = *(const float4*)(g.pos + (size_t)(1 + p) * g.D + n);                              \
-          }                                                                                             \
+          G256_SPLIT(rr, b, p);                                                                         \
+          (void)b;                                                                                      \
+          dst[it] = *(const float4*)(g.pos + (size_t)(1 + p) * g.D + n);                                \
         }                                                                                               \
       }                                                                                                 \
     }                                                                                                   \
@@ -391,10 +386,6 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm256(const GemmArgs g) {
       G256_SPLIT(rr, b, p);                                                                             \
       const float4 ps = pre[it];                                                                        \
       *(float4*)(g.x + (size_t)(b * g.Tp + g.G + p) * g.D + n) = make_float4(v.x + ps.x, v.y + ps.y, v.z + ps.z, v.w + ps.w); \
-    } else if constexpr (EPI == EPI_RESIDUAL) {                                                         \
-      float4 xo = pre[it];                                                                              \
-      xo.x += l4.x * v.x; xo.y += l4.y * v.y; xo.z += l4.z * v.z; xo.w += l4.w * v.w;                   \
-      *(float4*)(g.x + (size_t)m * g.N + n) = xo;                                                       \
     } else if constexpr (EPI == EPI_QKV) {       /* q or k columns of the last block */                 \
       const int which = n0 >= g.D ? 1 : 0;                                                              \
       const int hd = n - which * g.D, head = hd >> 6, d = hd & 63;                                      \
@@ -444,13 +435,14 @@ static hipError_t launch256_typed(GemmEpilogue epi, const GemmArgs& a, hipStream
   switch (epi) {
     case EPI_PATCH_EMBED: return launch256_one<T, EPI_PATCH_EMBED>(a, s);
     case EPI_QKV: return launch256_one<T, EPI_QKV>(a, s);
-    case EPI_RESIDUAL: return launch256_one<T, EPI_RESIDUAL>(a, s);
+    case EPI_RESIDUAL: return hipErrorInvalidValue;      // k_vit_gemm_roll
     case EPI_GELU: return launch256_one<T, EPI_GELU>(a, s);
   }
   return hipErrorInvalidValue;
 }
 
 bool vit_gemm256_fits(GemmEpilogue epi, const GemmArgs& a) {
+  if (epi == EPI_RESIDUAL) return false;      // proj / fc2 at 256 x 256 tiles are the rolling kernel's (vit_gemm_roll.hip)
   if (a.N % g256::TN != 0 || a.K % (2 * g256::TK) != 0 || a.lda % 8 != 0) return false;
   if (epi == EPI_QKV && (a.D % g256::TN != 0 || a.Tp % 8 != 0)) return false;
   if ((size_t)a.M * a.lda * 2 >= ((size_t)1 << 31) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 31)) return false;

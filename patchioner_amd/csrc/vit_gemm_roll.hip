@@ -35,6 +35,23 @@
 //                interval's DMA and wait, and every later wait keeps its k_vit_gemm256 count: a count of 4 still means "all
 //                but the two youngest half-tiles", and only ever forces OLDER stores to have completed as well (safe).
 //   bias         scalar loads (s_load, lgkmcnt) through inline asm with their own wait: no VGPR-destination load in the loop.
+//
+// proj / fc2 (EPI_RESIDUAL, round 5): x[m][n] += acc + b' with LayerScale folded into W and b at load.  The fp32 residual stream is 8 B
+// per element of traffic where q / k / fc1 outputs are 2, and in k_vit_gemm256 that read-modify-write was all exposed (proj: 31.6 k of a
+// tile's 62.8 k cycles).  Here neither half of it waits for the other or for the multiplies:
+//   * READ: the old x JOINS the running sum in the middle of the main loop (kernels.h, resid_join_ktile: one definition of the order for
+//     every GEMM kernel).  The accumulator is eight units of (quadrant, 32-row half); unit u's 32 x 32 patch per wave (4 KiB) is fetched
+//     by four LDS-DMA pieces into the wave's OWN 4 KiB of the staging image during K-tile u + 1 (issued after that K-tile's counted wait,
+//     so the next K-tile's wait retires it: every vmcnt keeps its meaning), read back in accumulator order in K-tile u + 2 -- the DMA
+//     deposits with the main ring's swizzle, so those reads are the conflict-free fragment pattern -- and added (16 VALU per wave).
+//   * WRITE: the finished units leave one per interval in the last K-tile and the next tile's first one: bias (SGPRs), four ds_write_b128
+//     in accumulator order into the same 4 KiB, four lane-linear ds_read_b128 (rows of 128 B), four 16-B buffer stores to the addresses
+//     the unit's x came from.  Everything a wave stages it reads back itself: no barrier, no cross-wave hazard; LDS operations of one
+//     wave execute in order, so a unit's reads precede the next unit's writes without a wait.
+//   Unit slots (u = 2 q + rt; L = last K-tile, F = first of the next tile; waves 0-3 run hooks after an interval's MFMAs, waves 4-7 before):
+//       waves 0-3:  L0 u0  L1 u1  L2 u2  L3 u3  F0 u4  F1 u5  F2 u6  F3 (before its MFMAs) u7
+//       waves 4-7:  L1 u0  L2 u1  L3 u2  F0 u3  F1 u4  F2 u5  F3 (before its MFMAs) u6, u7
+//   a unit is final after interval L(q) and its registers restart from zero in F(q): every slot lies between the two.
 #include "common.h"
 #include "kernels.h"
 
@@ -132,7 +149,7 @@ __device__ __forceinline__ float gelu_erf_plain(float v) {
 template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
   using namespace groll;
-  static_assert(EPI == EPI_QKV || EPI == EPI_GELU, "rolling epilogue: operand-precision outputs only");
+  static_assert(EPI == EPI_QKV || EPI == EPI_GELU || EPI == EPI_RESIDUAL, "rolling epilogue: q / k / V, fc1 + GELU, or the fp32 residual update");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const stage = smem + RING_BYTES;
   typedef typename Vec8<T>::type frag_t;
@@ -150,7 +167,8 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
   const int gq = gc / ntn, gr = gc - gq * ntn;           // id + gc -> (tm + gq, tn + gr) with one carry: no division in the loop
   int tmC = id / ntn, tnC = id - tmC * ntn;              // the tile being STAGED
   // bytes of an output tensor (the buffer stores' bound): q, k, vT [B][H][Tk][64] / out16 [M][N], operand precision
-  const int out_bytes = EPI == EPI_GELU ? (int)((size_t)g.M * g.N * 2) : (int)((size_t)(g.M / g.Tp) * g.H * g.Tk * 128);
+  const int out_bytes = EPI == EPI_RESIDUAL ? (int)((size_t)g.M * g.N * 4)
+                      : EPI == EPI_GELU     ? (int)((size_t)g.M * g.N * 2) : (int)((size_t)(g.M / g.Tp) * g.H * g.Tk * 128);
 
   const int prow = 8 * wid + (lane >> 3);
   const uint32_t kcs = (uint32_t)(((lane & 7) ^ ((4 * wid + (lane >> 4)) & 7)) * 16);
@@ -199,11 +217,9 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
   //   V tiles (qkv)       TRANSPOSED, [128 columns][256 B = 128 tokens]: neighbouring lanes (tokens r, r ^ 1) exchange halves
   //                       (DPP quad_perm + v_perm_b32) so that a lane writes one column's token PAIR (4 B); odd columns
   //                       sit 64 B further (bank-conflict-free: even lanes fill banks 0-15, odd lanes 16-31)
-#define ROLL_E12(q, I, J)                                                                                                   \
+  // bias of quadrant q (both 32-row halves) from SGPRs: lanes 0-31 / 32-63 hold different columns, two exec-masked runs
+#define ROLL_BIAS(q, J, _h)                                                                                                 \
   do {                                                                                                                      \
-    int _ln = lane;   /* opaque copy: keeps the hook's address arithmetic INSIDE the hook (hoisted out of the tile loop it */ \
-    asm volatile("" : "+v"(_ln));   /* would sit in registers the main loop needs and spill) */                            \
-    const int _h = _ln >> 5, _r31 = _ln & 31;                                                                               \
     const float* const _bp = g.bias + e_n0 + (J) * 128 + wc * 32;                                                           \
     _Pragma("unroll") for (int ah = 0; ah < 2; ++ah) {       /* 16 columns at a time: 16 SGPRs of bias */                   \
       i32x16 s_b;                                                                                                           \
@@ -229,6 +245,13 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
           }                                                                                                                 \
       }                                                                                                                     \
     }                                                                                                                       \
+  } while (0)
+#define ROLL_E12(q, I, J)                                                                                                   \
+  do {                                                                                                                      \
+    int _ln = lane;   /* opaque copy: keeps the hook's address arithmetic INSIDE the hook (hoisted out of the tile loop it */ \
+    asm volatile("" : "+v"(_ln));   /* would sit in registers the main loop needs and spill) */                            \
+    const int _h = _ln >> 5, _r31 = _ln & 31;                                                                               \
+    ROLL_BIAS(q, J, _h);                                                                                                    \
     if (EPI == EPI_QKV && e_n0 >= 2 * g.D) {          /* V tile: transposed image */                                        \
       const uint32_t _sel = (_ln & 1) ? 0x03020706u : 0x05040100u;                                                          \
       _Pragma("unroll") for (int rt = 0; rt < 2; ++rt) _Pragma("unroll") for (int a = 0; a < 4; ++a) {                      \
@@ -314,6 +337,80 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
       }                                                                                                                     \
     }                                                                                                                       \
   } while (0)
+  // ---- EPI_RESIDUAL hooks (file header): unit U = 2 q + rt of the tile at (MM0, NN0); everything is private to the wave.
+  // A unit's 4-KiB image holds its 32 rows x 128 B with the ring's swizzle: logical 16-B chunk c of row r sits in slot c ^ ((r >> 1) & 7).
+  // LDS-DMA piece `it` = rows 8 it .. 8 it + 7: lane L deposits at slot L & 7 of row 8 it + (L >> 3), so it fetches (and, on the way out,
+  // stores) logical chunk (L & 7) ^ ((4 it + (L >> 4)) & 7): one per-lane offset for even pieces, the same ^ 64 B for odd ones.
+  // Rows come in aligned groups of 8 and M % 8 == 0 (launcher): a piece lies wholly inside or outside M (scalar test).
+#define RES_GEOM(U, MM0, NN0)                                                                                               \
+    constexpr int _q = (U) >> 1, _rt = (U) & 1, _I = _q >> 1, _J = (_q == 1 || _q == 2) ? 1 : 0;                             \
+    int _ln = lane;                                                                                                         \
+    asm volatile("" : "+v"(_ln));                                                                                           \
+    const int _rowb = (MM0) + 128 * _I + 64 * wr + 32 * _rt;                                                                \
+    const uint32_t _sbase = (uint32_t)_rowb * (uint32_t)(g.N * 4) + (uint32_t)(((NN0) + 128 * _J + 32 * wc) * 4);           \
+    const uint32_t _vl = (uint32_t)(_ln >> 3) * (uint32_t)(g.N * 4) + (uint32_t)((((_ln & 7) ^ (_ln >> 4)) & 7) << 4);      \
+    const auto _rsx = __builtin_amdgcn_make_buffer_rsrc((void*)g.x, 0, out_bytes, 0x00020000);                              \
+    char* const _img = stage + wid * 4096
+#define RES_XDMA(U)                                                                                                         \
+  do {                                                                                                                      \
+    RES_GEOM(U, m0, n0);                                                                                                    \
+    (void)_q; (void)_rt;                                                                                                    \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it)                                                                        \
+      if (_rowb + 8 * it < g.M)                                                                                             \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(_rsx, (lds_ptr_t)(_img + it * 1024), 16, _vl ^ ((it & 1) ? 64u : 0u),      \
+                                                 _sbase + (uint32_t)(8 * it) * (uint32_t)(g.N * 4), 0, 0);                  \
+  } while (0)
+#define RES_XADD(U)                                                                                                         \
+  do {                                                                                                                      \
+    constexpr int _q = (U) >> 1, _rt = (U) & 1;                                                                             \
+    int _ln = lane;                                                                                                         \
+    asm volatile("" : "+v"(_ln));                                                                                           \
+    const char* const _b = stage + wid * 4096 + (_ln & 31) * 128;                                                           \
+    f32x4 _t[4];                                                                                                            \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) _t[a] = *(const f32x4*)(_b + co[a]);                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the reads have returned before the next unit's DMA is issued */ \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int e = 0; e < 4; ++e)                             \
+      acc[_q][_rt][4 * a + e] += _t[a][e];                                                                                  \
+  } while (0)
+#define RES_OUT(U)                                                                                                          \
+  do {                                                                                                                      \
+    RES_GEOM(U, e_m0, e_n0);                                                                                                \
+    if constexpr (_rt == 0) { const int _h = _ln >> 5; ROLL_BIAS(_q, _J, _h); }                                             \
+    char* const _b = _img + (_ln & 31) * 128;                                                                               \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                                           \
+      *(f32x4*)(_b + co[a]) = (f32x4){acc[_q][_rt][4 * a], acc[_q][_rt][4 * a + 1], acc[_q][_rt][4 * a + 2], acc[_q][_rt][4 * a + 3]}; \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                                      \
+      const u32x4 v = *(const u32x4*)(_img + it * 1024 + 16 * _ln);                                                         \
+      if (PIO_ROLL_ABL & 2) { asm volatile("" :: "v"(v)); continue; }                                                       \
+      if (_rowb + 8 * it < g.M)                                                                                             \
+        __builtin_amdgcn_raw_buffer_store_b128(v, _rsx, _vl ^ ((it & 1) ? 64u : 0u),                                        \
+                                               _sbase + (uint32_t)(8 * it) * (uint32_t)(g.N * 4), 0);                       \
+    }                                                                                                                       \
+  } while (0)
+#define RES_U(U) ((U) < 0 ? 0 : (U))
+  // one slot of the schedule: interval k of a K-tile at position POS, before (PRE) or at the group's usual place; U = the unit whose x
+  // joins in this K-tile (middle K-tiles 2 .. 9 of a tile), or -1
+#define RES_SLOT(POS, k, PRE, GRP, U)                                                                                       \
+  do {                                                                                                                      \
+    if constexpr (EPI == EPI_RESIDUAL) {                                                                                    \
+      if constexpr ((POS) == 1 && (k) == 3 && !(PRE)) RES_XDMA(0);                                                          \
+      if constexpr ((POS) == 2 && (U) >= 0) {                                                                               \
+        if constexpr ((GRP) == 0 ? (!(PRE) && (k) == ((U) >= 6 ? 2 : 3)) : ((PRE) && (k) == 3)) {                           \
+          RES_XADD(RES_U(U));                                                                                               \
+          if constexpr ((U) < 7) RES_XDMA(RES_U(U) + 1);                                                                    \
+        }                                                                                                                   \
+      }                                                                                                                     \
+      if constexpr ((GRP) == 0) {                                                                                           \
+        if constexpr ((POS) == 4 && !(PRE)) RES_OUT(k);                                                                     \
+        if constexpr ((POS) == 0 && !(PRE) && (k) <= 2) { if (has_prev) RES_OUT(4 + (k)); }                                 \
+        if constexpr ((POS) == 0 && (PRE)) { if (has_prev) RES_OUT(7); }                                                    \
+      } else {                                                                                                              \
+        if constexpr ((POS) == 4 && !(PRE) && (k) >= 1) RES_OUT(((k) - 1) & 7);                                             \
+        if constexpr ((POS) == 0 && !(PRE) && (k) <= 2) { if (has_prev) RES_OUT(3 + (k)); }                                 \
+        if constexpr ((POS) == 0 && (PRE)) { if (has_prev) { RES_OUT(6); RES_OUT(7); } }                                    \
+      }                                                                                                                     \
+    }                                                                                                                       \
+  } while (0)
   // the eight hook slots of the table in the file header
 #define ROLL_HOOK(slot)                                                                                                     \
   do {                                                                                                                      \
@@ -382,46 +479,57 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
   // the very first K-tile of the workgroup: A1 of K-tile 0 is still in flight after the prologue's wait
 #define ROLL_FIRSTWAIT(POS) do { if constexpr ((POS) == 0) { if (!has_prev) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } } while (0)
   // hooks of interval k (0..3) of a K-tile at position POS: slots L1..L3 in the last K-tile, F0..F3 in the first, S0 in the second
-#define ROLL_HOOKS(POS, k)                                                                        \
+#define ROLL_HOOKS(POS, k, GRP, U)                                                                       \
   do {                                                                                                   \
-    if constexpr ((POS) == 4 && (k) >= 1) ROLL_HOOK((k));                                         \
-    if constexpr ((POS) == 0 && (k) <= 2) { if (has_prev) ROLL_HOOK(4 + (k)); }                   \
-    if constexpr ((POS) == 1 && (k) == 0) { if (has_prev) ROLL_HOOK(8); }                         \
+    if constexpr (EPI == EPI_RESIDUAL) {                                                                 \
+      RES_SLOT(POS, k, 0, GRP, U);                                                                       \
+    } else {                                                                                             \
+      if constexpr ((POS) == 4 && (k) >= 1) ROLL_HOOK((k));                                              \
+      if constexpr ((POS) == 0 && (k) <= 2) { if (has_prev) ROLL_HOOK(4 + (k)); }                        \
+      if constexpr ((POS) == 1 && (k) == 0) { if (has_prev) ROLL_HOOK(8); }                              \
+    }                                                                                                    \
   } while (0)
   // slot 7 (E12 of Q10) comes BEFORE the MFMAs of interval F3, which overwrite Q10
-#define ROLL_PREHOOK3(POS) do { if constexpr ((POS) == 0) { if (has_prev) ROLL_HOOK(7); } } while (0)
+#define ROLL_PREHOOK3(POS, GRP, U)                                                                       \
+  do {                                                                                                   \
+    if constexpr (EPI == EPI_RESIDUAL) {                                                                 \
+      RES_SLOT(POS, 3, 1, GRP, U);                                                                       \
+    } else {                                                                                             \
+      if constexpr ((POS) == 0) { if (has_prev) ROLL_HOOK(7); }                                          \
+    }                                                                                                    \
+  } while (0)
 
   // waves 0-3: MFMAs of interval k, then the fragment reads of interval k + 1, the LDS-DMA, the hooks
-#define ROLL_KTILE_G0(POS, t, BUF)                                                                \
+#define ROLL_KTILE_G0(POS, t, BUF, U)                                                                    \
   do {                                                                                                   \
     ROLL_MMA(0, fb0, (POS) == 0); ROLL_SB(); ROLL_READ_B(fb1, BUF, 1); ROLL_DMA0(POS, t, BUF); ROLL_FIRSTWAIT(POS); \
-    ROLL_SB(); ROLL_HOOKS(POS, 0); ROLL_BARRIER();                                                \
+    ROLL_SB(); ROLL_HOOKS(POS, 0, 0, U); ROLL_BARRIER();                                                 \
     ROLL_MMA(1, fb1, (POS) == 0); ROLL_SB(); ROLL_READ_A(BUF, 1); ROLL_DMA1(POS, t, BUF);                \
-    ROLL_SB(); ROLL_HOOKS(POS, 1); ROLL_BARRIER();                                                \
+    ROLL_SB(); ROLL_HOOKS(POS, 1, 0, U); ROLL_BARRIER();                                                 \
     ROLL_MMA(2, fb1, (POS) == 0); ROLL_SB(); ROLL_DMA2(POS, t, BUF); ROLL_WAIT2(POS);                    \
-    ROLL_SB(); ROLL_HOOKS(POS, 2); ROLL_BARRIER();                                                \
-    ROLL_PREHOOK3(POS); ROLL_SB();                                                                \
+    ROLL_SB(); ROLL_HOOKS(POS, 2, 0, U); ROLL_BARRIER();                                                 \
+    ROLL_PREHOOK3(POS, 0, U); ROLL_SB();                                                                 \
     ROLL_MMA(3, fb0, (POS) == 0); ROLL_SB();                                                             \
     if ((POS) < 4 || has_next) { ROLL_READ_A((BUF) ^ 1, 0); ROLL_READ_B(fb0, (BUF) ^ 1, 0); }            \
     ROLL_DMA3(POS, t, BUF);                                                                              \
-    ROLL_SB(); ROLL_HOOKS(POS, 3); ROLL_BARRIER();                                                \
+    ROLL_SB(); ROLL_HOOKS(POS, 3, 0, U); ROLL_BARRIER();                                                 \
   } while (0)
   // waves 4-7: the hooks, the fragment reads of interval k, the LDS-DMA, then the MFMAs of interval k
-#define ROLL_KTILE_G1(POS, t, BUF)                                                                \
+#define ROLL_KTILE_G1(POS, t, BUF, U)                                                                    \
   do {                                                                                                   \
-    ROLL_HOOKS(POS, 0); ROLL_SB();                                                                \
+    ROLL_HOOKS(POS, 0, 1, U); ROLL_SB();                                                                 \
     ROLL_READ_A(BUF, 0); ROLL_READ_B(fb0, BUF, 0); ROLL_DMA0(POS, t, BUF); ROLL_SB(); ROLL_MMA(0, fb0, (POS) == 0); \
     ROLL_FIRSTWAIT(POS); ROLL_BARRIER();                                                                 \
-    ROLL_HOOKS(POS, 1); ROLL_SB();                                                                \
+    ROLL_HOOKS(POS, 1, 1, U); ROLL_SB();                                                                 \
     ROLL_READ_B(fb1, BUF, 1); ROLL_DMA1(POS, t, BUF); ROLL_SB(); ROLL_MMA(1, fb1, (POS) == 0); ROLL_BARRIER(); \
-    ROLL_HOOKS(POS, 2); ROLL_SB();                                                                \
+    ROLL_HOOKS(POS, 2, 1, U); ROLL_SB();                                                                 \
     ROLL_READ_A(BUF, 1); ROLL_DMA2(POS, t, BUF); ROLL_SB(); ROLL_MMA(2, fb1, (POS) == 0); ROLL_WAIT2(POS); ROLL_BARRIER(); \
-    ROLL_PREHOOK3(POS); ROLL_HOOKS(POS, 3); ROLL_SB();                                     \
+    ROLL_PREHOOK3(POS, 1, U); ROLL_HOOKS(POS, 3, 1, U); ROLL_SB();                                       \
     ROLL_DMA3(POS, t, BUF); ROLL_SB(); ROLL_MMA(3, fb0, (POS) == 0); ROLL_BARRIER();                     \
   } while (0)
 
   // ---- the tile walk of one wave group
-#define ROLL_WALK(KTILE)                                                                                 \
+#define ROLL_WALK(KTILE, GRP)                                                                            \
   do {                                                                                                   \
     bool has_prev = false;                                                                               \
     int _ti = 0; (void)_ti;                                                                               \
@@ -429,15 +537,21 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
       const int nid = id + gc;                                                                           \
       const bool has_next = nid < ntiles;                                                                \
       ROLL_STAMP(2 + 5 * _ti);                                                                           \
-      KTILE(0, 0, 0);                                                                                    \
-      KTILE(1, 1, 1);                                                                                    \
+      KTILE(0, 0, 0, -1);                                                                                \
+      KTILE(1, 1, 1, -1);                                                                                \
       ROLL_STAMP(3 + 5 * _ti);                                                                           \
-      for (int t = 2; t < nk - 2; t += 2) { KTILE(2, t, 0); KTILE(2, t + 1, 1); }          \
+      if constexpr (EPI == EPI_RESIDUAL) {      /* K-tiles 2 .. 9: the old x joins, one unit per K-tile (nk >= 12: launcher) */ \
+        KTILE(2, 2, 0, 0); KTILE(2, 3, 1, 1); KTILE(2, 4, 0, 2); KTILE(2, 5, 1, 3);                      \
+        KTILE(2, 6, 0, 4); KTILE(2, 7, 1, 5); KTILE(2, 8, 0, 6); KTILE(2, 9, 1, 7);                      \
+        for (int t = 10; t < nk - 2; t += 2) { KTILE(2, t, 0, -1); KTILE(2, t + 1, 1, -1); }             \
+      } else {                                                                                           \
+        for (int t = 2; t < nk - 2; t += 2) { KTILE(2, t, 0, -1); KTILE(2, t + 1, 1, -1); }              \
+      }                                                                                                  \
       ROLL_STAMP(4 + 5 * _ti);                                                                           \
-      KTILE(3, nk - 2, 0);                                                                               \
+      KTILE(3, nk - 2, 0, -1);                                                                           \
       ROLL_STAMP(5 + 5 * _ti);                                                                           \
       e_m0 = m0; e_n0 = n0; e_img0 = m0 / per; e_row0 = m0 - e_img0 * per;                               \
-      KTILE(4, nk - 1, 1);                                                                               \
+      KTILE(4, nk - 1, 1, -1);                                                                           \
       ROLL_STAMP(6 + 5 * _ti); ++_ti;                                                                    \
       has_prev = true;                                                                                   \
       if (!has_next) break;                                                                              \
@@ -445,11 +559,16 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
       m0 = tmC * TM; n0 = tnC * TN;                                                                      \
     }                                                                                                    \
     /* drain: the last tile's slots F0 .. S0 with nothing left to multiply */                            \
-    ROLL_HOOK(4); ROLL_BARRIER();                                                                 \
-    ROLL_HOOK(5); ROLL_BARRIER();                                                                 \
-    ROLL_HOOK(6); ROLL_BARRIER();                                                                 \
-    ROLL_HOOK(7); ROLL_BARRIER();                                                                 \
-    ROLL_HOOK(8);                                                                                        \
+    if constexpr (EPI == EPI_RESIDUAL) {                                                                 \
+      if constexpr ((GRP) == 1) RES_OUT(3);                                                              \
+      RES_OUT(4); RES_OUT(5); RES_OUT(6); RES_OUT(7);                                                    \
+    } else {                                                                                             \
+      ROLL_HOOK(4); ROLL_BARRIER();                                                                      \
+      ROLL_HOOK(5); ROLL_BARRIER();                                                                      \
+      ROLL_HOOK(6); ROLL_BARRIER();                                                                      \
+      ROLL_HOOK(7); ROLL_BARRIER();                                                                      \
+      ROLL_HOOK(8);                                                                                      \
+    }                                                                                                    \
     ROLL_STAMP(2 + 5 * _ti);                                                                             \
   } while (0)
 
@@ -467,9 +586,9 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
 
   if (wr == 0) {
     ROLL_READ_A(0, 0); ROLL_READ_B(fb0, 0, 0);
-    ROLL_WALK(ROLL_KTILE_G0);
+    ROLL_WALK(ROLL_KTILE_G0, 0);
   } else {
-    ROLL_WALK(ROLL_KTILE_G1);
+    ROLL_WALK(ROLL_KTILE_G1, 1);
   }
 }
 
@@ -490,13 +609,26 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
 #undef ROLL_HOOK
 #undef ROLL_E3
 #undef ROLL_E12
+#undef ROLL_BIAS
+#undef RES_SLOT
+#undef RES_U
+#undef RES_OUT
+#undef RES_XADD
+#undef RES_XDMA
+#undef RES_GEOM
 #undef ROLL_SPLIT
 #undef ROLL_OFFSETS
 
 // The rolling kernel serves the GEMMs whose tiles outnumber the CUs enough to give every workgroup a second tile to hide
-// the first one's epilogue under (qkv without the fp32 capture, fc1): from 1.5 tiles per CU on.
+// the first one's epilogue under (qkv without the fp32 capture, fc1): from 1.5 tiles per CU on; and proj / fc2 (EPI_RESIDUAL) at every
+// size the 256 x 256 tile is worth taking: the old x joins the sum inside the main loop even when a workgroup has one tile.
 bool vit_gemm_roll_fits(GemmEpilogue epi, const GemmArgs& a) {
   using namespace groll;
+  if (epi == EPI_RESIDUAL) {
+    if (a.M <= 0 || a.M % 8 != 0 || a.N % TN != 0 || a.K % (2 * TK) != 0 || a.K / TK < 12 || a.lda % 8 != 0) return false;
+    if ((size_t)a.M * a.lda * 2 >= ((size_t)1 << 31) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 31)) return false;
+    return (size_t)a.M * a.N * 4 < ((size_t)1 << 31);      // 32-bit byte offsets into x
+  }
   if (epi != EPI_QKV && epi != EPI_GELU) return false;
   if (epi == EPI_QKV && (a.qkv_last != nullptr || a.D % TN != 0 || a.Tp % 8 != 0 || a.N != 3 * a.D)) return false;
   if (a.M <= 0 || a.N % TN != 0 || a.K % (2 * TK) != 0 || a.K / TK < 4 || a.lda % 8 != 0) return false;
@@ -535,6 +667,7 @@ static hipError_t launch_roll_one(const GemmArgs& a, hipStream_t s) {
 hipError_t launch_vit_gemm_roll(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
   if (!vit_gemm_roll_fits(epi, a)) return hipErrorInvalidValue;
   if (epi == EPI_QKV) return t == OP_F16 ? launch_roll_one<f16, EPI_QKV>(a, s) : launch_roll_one<bf16, EPI_QKV>(a, s);
+  if (epi == EPI_RESIDUAL) return t == OP_F16 ? launch_roll_one<f16, EPI_RESIDUAL>(a, s) : launch_roll_one<bf16, EPI_RESIDUAL>(a, s);
   return t == OP_F16 ? launch_roll_one<f16, EPI_GELU>(a, s) : launch_roll_one<bf16, EPI_GELU>(a, s);
 }
 

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <algorithm>
 #include <random>
 #include <string>
@@ -67,7 +68,7 @@ static GemmArgs args_for(const Bufs& b, const Case& c) {
   GemmArgs g; memset(&g, 0, sizeof(g));
   const int D = b.D;
   g.T = b.T; g.Tp = b.Tp; g.Tk = b.Tk; g.G = b.G; g.n2 = b.n2; g.D = D; g.H = b.H;
-  g.x = b.x; g.q = b.q; g.k = b.k; g.vT = b.v; g.bias = b.bias; g.ls = b.ls; g.out16 = b.out16; g.pos = b.pos;
+  g.x = b.x; g.q = b.q; g.k = b.k; g.vT = b.v; g.bias = b.bias; g.out16 = b.out16; g.pos = b.pos;
   g.M = b.M;
   switch (c.which) {
     case 0: case 5: g.A = b.A; g.lda = D; g.W = b.W; g.N = 3 * D; g.K = D; g.qkv_last = c.which == 5 ? b.cap : nullptr; break;
@@ -109,7 +110,7 @@ static int check(int B, int side, int D, bool bf) {
   int bad = 0;
   for (const Case& c : CASES) {
     GemmArgs g = args_for(b, c);
-    if (!vit_gemm256_fits(c.e, g) ) { printf("  %s: shape not served by the new kernels\n", c.name); continue; }
+    if (!vit_gemm256_fits(c.e, g) && !vit_gemm_roll_fits(c.e, g)) { printf("  %s: shape not served by the new kernels\n", c.name); continue; }
     reset_outputs(b);
     CK(launch_vit_gemm(op, c.e, g, 0)); CK(hipDeviceSynchronize());
     const std::vector<uint8_t> ref = snapshot(b);
@@ -123,6 +124,21 @@ static int check(int B, int side, int D, bool bf) {
       for (size_t i = 0; i < ref.size(); ++i) if (ref[i] != got[i]) { if (!nd) first = i; ++nd; }
       if (nd) printf("  %s rep %d: %zu differing bytes of %zu (first at %zu; out16 %zu | q | k | v %zu each | x %zu | cap)\n", c.name, rep, nd,
                      ref.size(), first, b.sz_out16, b.sz_qk, b.sz_x);
+      if (nd && c.e == EPI_RESIDUAL && rep < NVAR) {       // which units of the 256-grid differ, and by how much
+        const float* xr = (const float*)(ref.data() + b.sz_out16 + 3 * b.sz_qk);
+        const float* xg = (const float*)(got.data() + b.sz_out16 + 3 * b.sz_qk);
+        size_t cnt[8] = {0}, tot[8] = {0}; double worst = 0; size_t tcol[16] = {0};
+        for (int m = 0; m < g.M; ++m) for (int n = 0; n < g.N; ++n) {
+          const int u = resid_unit(m, n); ++tot[u];
+          const float a = xr[(size_t)m * g.N + n], bb = xg[(size_t)m * g.N + n];
+          if (a != bb) { ++cnt[u]; ++tcol[(n / 256) & 15]; worst = std::max(worst, (double)fabsf(a - bb) / (fabs(a) + 1e-30)); }
+        }
+        printf("    differing elements per unit:");
+        for (int u = 0; u < 8; ++u) printf(" u%d %zu/%zu", u, cnt[u], tot[u]);
+        printf("\n    per column tile:");
+        for (int t = 0; t < g.N / 256; ++t) printf(" %zu", tcol[t]);
+        printf("   worst relative difference %.3e\n", worst);
+      }
       worst = std::max(worst, nd);
     }
     // non-trivial output guard: the reference must have written something
@@ -137,7 +153,6 @@ static int check(int B, int side, int D, bool bf) {
 
 static void time_all(int B, int side, int D) {
   Bufs b = make(B, side, D, false);
-  CK(hipMemset(b.ls, 0, D * 4));              // x stays bounded over repeated residual launches
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int rounds = 7, it = 10;
   printf("B=%d (M=%d), D=%d, T=%d      median us (TFLOP/s): old 128-tile kernel | 256 kernel | rolling\n", B, b.M, D, b.T);
@@ -161,7 +176,12 @@ static void time_all(int B, int side, int D) {
     printf("  %s %6dx%4dx%4d ", c.name, g.M, g.N, g.K);
     const int mult = c.which <= 3 ? 12 : (c.which == 4 ? 1 : 0);   // launches per 12-block forward (11 + 1 qkv with capture ignored)
     for (int which = 0; which < 1 + NVAR; ++which) {
-      if (tt[which].empty()) { printf(" |      -        "); if (which == NVAR && !tt[1].empty()) tot[which] += mult * tt[1][tt[1].size() / 2]; continue; }
+      if (tt[which].empty()) {        // a kernel that does not serve the shape: its column takes the other 256-tile kernel's time
+        printf(" |      -        ");
+        const int other = which == NVAR ? 1 : NVAR;
+        if (which >= 1 && !tt[other].empty()) { std::vector<float> o = tt[other]; std::sort(o.begin(), o.end()); tot[which] += mult * o[o.size() / 2]; }
+        continue;
+      }
       std::sort(tt[which].begin(), tt[which].end());
       const double us = tt[which][tt[which].size() / 2];
       printf(" | %7.1f (%5.0f)", us, fl / us / 1e6);
@@ -186,7 +206,6 @@ __global__ __launch_bounds__(256) void k_sweep(const float4* __restrict__ p, siz
 }
 static void time_cold(int B, int side, int D) {
   Bufs b = make(B, side, D, false);
-  CK(hipMemset(b.ls, 0, D * 4));
   float* sw; float* sink; const size_t big = (size_t)768 << 20;
   CK(hipMalloc(&sw, big)); CK(hipMalloc(&sink, 64)); CK(hipMemset(sw, 0, big));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -216,7 +235,6 @@ static void time_cold(int B, int side, int D) {
 // where a tile's cycles go: s_memtime stamps of every workgroup (entry, first operands landed, main loop done, end)
 static void stamps(int B, int side, int D) {
   Bufs b = make(B, side, D, false);
-  CK(hipMemset(b.ls, 0, D * 4));
   const int maxwg = 4096;
   unsigned long long* dbuf; CK(hipMalloc(&dbuf, maxwg * 4 * 8));
   std::vector<unsigned long long> h(maxwg * 4);
@@ -250,7 +268,6 @@ static void stamps(int B, int side, int D) {
 // K-tiles, its last two (with its own hooks), and the final drain
 static void roll_stamps_report(int B, int side, int D) {
   Bufs b = make(B, side, D, false);
-  CK(hipMemset(b.ls, 0, D * 4));
   unsigned long long* dbuf; CK(hipMalloc(&dbuf, 256 * 64 * 8));
   std::vector<unsigned long long> h(256 * 64);
   for (const Case& c : CASES) {
@@ -290,6 +307,7 @@ static void roll_stamps_report(int B, int side, int D) {
 int main(int argc, char** argv) {
   setenv("PIO_GEMM256_MIN_TILES", "0", 1);     // launch_vit_gemm stays the 128-tile kernel here: it is the reference column
   setenv("PIO_GEMM_ROLL_MIN_TILES", "0", 1);
+  setenv("PIO_GEMM_RRES_MIN_TILES", "0", 1);
   const std::string mode = argc > 1 ? argv[1] : "both";
   std::vector<int> Bs;
   for (int i = 2; i < argc; ++i) Bs.push_back(atoi(argv[i]));

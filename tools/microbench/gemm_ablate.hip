@@ -20,7 +20,7 @@ int main() {
   CK(hipMemcpy(W, h.data(), (size_t)4 * D * D * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(W4, h.data(), (size_t)4 * D * D * 2, hipMemcpyHostToDevice));
   CK(hipMemset(bias, 0, 4 * D * 4)); CK(hipMemset(x, 0, (size_t)M * D * 4)); CK(hipMemset(ls, 0, D * 4));
   GemmArgs g; memset(&g, 0, sizeof(g));
-  g.T = T; g.Tp = Tp; g.Tk = 320; g.G = 5; g.n2 = 256; g.D = D; g.H = 12; g.x = x; g.q = q; g.k = k; g.vT = v; g.bias = bias; g.ls = ls; g.out16 = out16;
+  g.T = T; g.Tp = Tp; g.Tk = 320; g.G = 5; g.n2 = 256; g.D = D; g.H = 12; g.x = x; g.q = q; g.k = k; g.vT = v; g.bias = bias; g.out16 = out16;
   struct Case { const char* name; GemmEpilogue e; const void* A; int lda, N, K; const void* W; } cases[] = {
     {"qkv  4224x2304x768 ", EPI_QKV, A, D, 3 * D, D, W}, {"proj 4224x768x768  ", EPI_RESIDUAL, A, D, D, D, W},
     {"fc1  4224x3072x768 ", EPI_GELU, A, D, 4 * D, D, W}, {"fc2  4224x768x3072 ", EPI_RESIDUAL, A4, 4 * D, D, 4 * D, W4}};
