@@ -346,10 +346,12 @@ def main():
 
     P = max(1, args.in_flight)
     S = max(1, args.stage_streams)
-    VB = max(1, min(args.vit_batches, P)) if args.mode == "group" else 1
+    VB = max(1, args.vit_batches) if args.mode == "group" and P > 1 else 1       # a ViT launch may feed the tail of one decode group and the head of the next
     DS = max(1, args.decode_streams)
+    VB_BIG = 10          # the second launch size measured beside the default (`vit_launch_160`): 160 images per ViT launch
     models = build_models(local, P if args.mode == "streams" else S,
-                          max_prefixes=min(256, max(64, BATCH * P)) if args.mode == "group" else 64, max_batch=BATCH * VB)
+                          max_prefixes=min(256, max(64, BATCH * P)) if args.mode == "group" else 64,
+                          max_batch=BATCH * (max(VB, VB_BIG) if args.mode == "group" and P > 1 else VB))
     model = models[0]
     streams = [torch.cuda.Stream() for _ in range(P)]
     imgs, traces = make_inputs()
@@ -484,6 +486,47 @@ def main():
         prof_alone = model.engine.profile_read()
         model.engine.profile_enable(False)
         del big
+    # ... and the other launch size: 160 images per ViT launch (10 batches; a launch feeds the tail of one decode group and the head
+    # of the next).  proj / fc2 then have two 256-tiles per workgroup, so that the second tile's multiplies run beside the first
+    # one's stores (vit_gemm_roll.hip).  Its own pipeline on the same model, the same K steps timed the same way, the same two
+    # brackets: `vit_launch_160`.  `value` stays the default launch size.
+    big_launch = None
+    if pipe is not None and VB != VB_BIG and os.environ.get("PIO_BENCH_NO_160", "0") != "1":
+        from patchioner_amd.pipeline import TraceCaptionPipeline
+        pipe.close()
+        pipe10 = TraceCaptionPipeline(model, group_batches=P, stage_replicas=models[1:S], vit_batches=VB_BIG, decode_clones=DS - 1)
+
+        def run10(n):
+            seen = None
+            for _ in pipe10.run((imgs, traces) for _ in range(n)):
+                if pipe10.last_ids is not seen:
+                    seen = pipe10.last_ids
+                    pdist.all_gather_equal_ids(seen)
+        import math
+        run10(math.lcm(P, VB_BIG))
+        fence()
+        t10 = time.perf_counter()
+        run10(args.steps)
+        fence()
+        dt10 = time.perf_counter() - t10
+        model.engine.profile_enable(True)
+        run10(math.lcm(P, VB_BIG))
+        torch.cuda.synchronize()
+        prof10 = model.engine.profile_read()
+        model.engine.profile_enable(False)
+        pipe10.close()
+        big = torch.cat([imgs] * VB_BIG)
+        for _ in range(2):
+            model.engine.vit_forward(big, want_qkv=True)
+        torch.cuda.synchronize()
+        model.engine.profile_enable(True)
+        for _ in range(4):
+            model.engine.vit_forward(big, want_qkv=True)
+        torch.cuda.synchronize()
+        prof10a = model.engine.profile_read()
+        model.engine.profile_enable(False)
+        del big
+        big_launch = (dt10, prof10, prof10a)
     assert len(outs["trace_capts"]) == BATCH and ids.shape[0] == BATCH * world
     # Image transforms (the reference times them apart from inference, eval_trace_captioning.py:233-262): 16 camera-sized
     # RGB images -> [16,3,224,224] on the device (pio_preprocess: raw pixels over PCIe, resize / crop / normalise on the
@@ -588,6 +631,11 @@ def main():
             "roofline": roof,
             "roofline_in_pipeline": roof_pipe,
             "roofline_sync": roof_sync,
+            "vit_launch_160": None if big_launch is None else {
+                "value": BATCH * world * args.steps / big_launch[0], "unit": "captions/s", "steps": args.steps,
+                "note": "the same K steps through TraceCaptionPipeline with 160 images per ViT launch (10 batches); rank 0's clock",
+                "roofline": roofline_of(big_launch[2]["vit_gemm"], BATCH * VB_BIG, "160 images per launch, nothing else in flight", None),
+                "roofline_in_pipeline": roofline_of(big_launch[1]["vit_gemm"], BATCH * VB_BIG, "160 images per launch inside the pipelined region", None)},
             "sync": {"value": BATCH * world * sync_steps / dt_sync, "unit": "captions/s", "steps": sync_steps,
                      "ms_per_step": dt_sync / sync_steps * 1e3,
                      "note": "one forward at a time (batches_in_flight = 1), the reference eval scripts' call pattern"},
@@ -595,7 +643,7 @@ def main():
             "preprocess": prep,
         }
         if not args.no_configs and world == 1:           # BASELINE configs 3 / 4 / 5, per-GPU shards (N = 1 only: keeps an N-rank run inside the driver's budget)
-            if pipe is not None:
+            if pipe is not None and big_launch is None:
                 pipe.close()
             line["configs"] = other_configs(local)
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)

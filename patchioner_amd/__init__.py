@@ -18,6 +18,22 @@ _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 # (one bench run in ~40 lost 17 % that way).  Eight queues: nothing to alias, same throughput (8.64 against 8.62-8.66 k captions/s).  Same rules
 # as above: read at runtime initialisation, never over the user's own value.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Both are PROCESS-WIDE: every HIP user of this process (torch, RCCL) runs with them, and they are read ONCE, when the HIP runtime
+# initialises -- a process that has made a GPU call before `import patchioner_amd` keeps whatever it started with (the defaults above then
+# change nothing; pipeline.py says so in its warning).  INTEGRATION.md, "process-wide settings".
+
+
+def runtime_already_initialised() -> bool:
+    """True when the HIP runtime was up before the defaults above could take effect (best effort: torch's own view of it)."""
+    try:
+        import sys as _sys
+        t = _sys.modules.get("torch")
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:                                   # noqa: BLE001 -- never fail an import over a diagnostic
+        return False
+
+
+_HIP_UP_AT_IMPORT = runtime_already_initialised()
 
 
 def __getattr__(name):  # lazy: importing the package must not require a GPU or the built library

@@ -133,7 +133,7 @@ struct pio_context {
   struct PKey { int N, P, steps; bool operator<(const PKey& o) const { return N != o.N ? N < o.N : (P != o.P ? P < o.P : steps < o.steps); } };
   // prompted-decode graphs, keyed by (rows, prompt positions, steps).  The prompt length follows the hard prompt of every batch,
   // so a long run meets many keys: the cache is a small LRU (a graph is ~ (P + steps) x 60 kernel nodes) and evicted execs are destroyed.
-  struct PGraph { hipGraphExec_t exec; uint64_t last_use; hipStream_t last_stream; };
+  struct PGraph { hipGraphExec_t exec; uint64_t last_use; hipEvent_t done; };     // done: recorded behind the graph's last launch (valid after the caller's stream has gone)
   std::map<PKey, PGraph> pgraphs;
   uint64_t pgraph_clock = 0;
   static constexpr size_t kMaxPGraphs = 12;
@@ -774,7 +774,7 @@ int pio_destroy(pio_handle c) {
   (void)hipSetDevice(c->cfg.device);
   (void)hipDeviceSynchronize();
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.second);
-  for (auto& g : c->pgraphs) (void)hipGraphExecDestroy(g.second.exec);
+  for (auto& g : c->pgraphs) { (void)hipGraphExecDestroy(g.second.exec); if (g.second.done) (void)hipEventDestroy(g.second.done); }
   for (void* p : c->allocs) (void)hipFree(p);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto& sl : c->prep_slots) {
@@ -1448,16 +1448,21 @@ int pio_viecap_decode(pio_handle c, const float* cont, const int32_t* tokens, in
         auto old = c->pgraphs.begin();
         for (auto jt = c->pgraphs.begin(); jt != c->pgraphs.end(); ++jt)
           if (jt->second.last_use < old->second.last_use) old = jt;
-        HIP_OK(hipStreamSynchronize(old->second.last_stream));   // it may still be running on the stream it was last launched on
-        if (old->second.last_stream != s) HIP_OK(hipStreamSynchronize(s));
+        // it may still be running where it was last launched: wait for the event recorded behind that launch (an event outlives the
+        // caller's stream; round 4 synchronised the stored stream handle, which a caller may have destroyed since -- the error then
+        // left the new exec leaked and the dead entry in place for every later decode).  Whatever the wait says, the entry goes.
+        if (old->second.done) { (void)hipEventSynchronize(old->second.done); (void)hipEventDestroy(old->second.done); }
         (void)hipGraphExecDestroy(old->second.exec);
         c->pgraphs.erase(old);
       }
-      it = c->pgraphs.emplace(key, pio_context::PGraph{exec, 0, s}).first;
+      hipEvent_t done = nullptr;
+      const hipError_t ee = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+      if (ee != hipSuccess) { (void)hipGraphExecDestroy(exec); HIP_OK(ee); }
+      it = c->pgraphs.emplace(key, pio_context::PGraph{exec, 0, done}).first;
     }
     it->second.last_use = ++c->pgraph_clock;
-    it->second.last_stream = s;
     HIP_OK(hipGraphLaunch(it->second.exec, s));
+    HIP_OK(hipEventRecord(it->second.done, s));
   } else {
     HIP_OK(launch_decode_prompted(a, c->prompt_buf, P, s));
   }

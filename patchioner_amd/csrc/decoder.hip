@@ -33,16 +33,9 @@
 
 namespace pio {
 
-// diagnostic ablations (tools/microbench/dec_bench.hip); all off in the shipped library
-#ifndef PIO_DABL_NOX
-#define PIO_DABL_NOX 0
-#endif
-#ifndef PIO_DABL_NOSPLIT     // 1: k_dec_gemm_s stages its activations without the split arithmetic and the row sums
-#define PIO_DABL_NOSPLIT 0
-#endif
-#ifndef PIO_DABL_NOMFMA      // 2: every fp32 MFMA of this file on a 2-pass instruction (a quarter of the pipe time, same dataflow); 1: only the first sixth of every layer GEMM's fp32 MFMAs is issued (what a split-fp16 form would cost the matrix pipe: 3 / 16)
-#define PIO_DABL_NOMFMA 0
-#endif
+// (Round 5: the timing ablations that produced wrong results by design -- PIO_DABL_NOX / NOSPLIT / NOMFMA, PIO_LMF16_ABL, PIO_DEC_DENSE -- and the
+// fence-based split-K ticket that the relaxed-atomic one replaced have left this file; their numbers are in DESIGN.md section 5 and
+// profiles/r04_*, the code in the git history of round 4.)
 // minimum waves per SIMD requested for k_dec_gemm.  (5 => <= 96 VGPRs would let decode waves sit beside two
 // 208-register ViT GEMM waves when batches are pipelined on several streams; measured: it spills and is slower
 // both alone, 6.6 vs 5.8 ms per 30 steps, and pipelined, 2586 vs 2984 captions/s.)
@@ -70,9 +63,6 @@ namespace pio {
 #ifndef PIO_LMF16_CPW8        // 16-column groups per wave of k_lmhead_f16 at 65 .. 128 prefixes (2: half the X~ fragment reads per MFMA, 197 instead of
 #define PIO_LMF16_CPW8 1      // 393 workgroups; measured 6.82 against 6.75 ms per decode(128) and no difference through the pipeline: 1)
 #endif
-#ifndef PIO_LMF16_ABL         // timing ablations of k_lmhead_f16 (diagnostic builds only): 1 no epilogue, 2 no X~ DMA, 3 no MFMA
-#define PIO_LMF16_ABL 0
-#endif
 #ifndef PIO_LMF16_FUSED       // <= 16 prefixes: statistics / fp16 conversion inside the head kernel
 #define PIO_LMF16_FUSED 1
 #endif
@@ -90,12 +80,6 @@ namespace pio {
 #endif
 #ifndef PIO_LMHEAD_CG
 #define PIO_LMHEAD_CG 1
-#endif
-#ifndef PIO_DEC_DENSE          // diagnostic: fewer, larger workgroups for the layer GEMMs above 64 prefixes (1: 64 rows x 64 columns, 2: 64 x 32)
-#define PIO_DEC_DENSE 0
-#endif
-#ifndef PIO_DEC_LEAN_TICKET   // split-K slabs through agent-scope relaxed atomics (sc1 accesses) instead of release / acquire fences (round 4)
-#define PIO_DEC_LEAN_TICKET 1
 #endif
 
 static constexpr int DEC_MAX_COLGROUPS = 128;  // split-K counters / slabs: Nout <= 1024 at <= 128 prefixes, fc2's 24 x 4 tiles at 256 (kernels.h: DEC_SPLITK_*)
@@ -117,13 +101,7 @@ typedef _Float16 dec_h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 dec_h4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ f32x4 mfma16f(float a, float b, f32x4 c) {
-#if PIO_DABL_NOMFMA == 2   // timing ablation: the same operands and dependences on a 2-pass instruction (8 instead of 32 cycles of the matrix pipe); wrong results
-  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
-#else
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-#endif
-}
+__device__ __forceinline__ f32x4 mfma16f(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // torch.argmax order: NaN counts as the maximum, ties (and several NaNs) go to the lowest index.  A prefix of NaNs
 // (the reference's mean over an empty box region) therefore decodes to token 0, as in the reference, instead of
@@ -283,10 +261,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? PIO_DEC_GEMM_WAVES : 1) void k
       for (int c = 0; c < HC; ++c) xb[c] = *(const float4*)(s_x + li * 772 + (k0 - kbase) + 16 * (HC + c));
     } else {
 #pragma unroll
-    for (int c = 0; c < HC; ++c) xa[c] = PIO_DABL_NOX ? make_float4(0.5f, 0.25f, 1.f, 2.f) : *(const float4*)(xp + 16 * c);
+    for (int c = 0; c < HC; ++c) xa[c] = *(const float4*)(xp + 16 * c);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int c = 0; c < HC; ++c) xb[c] = PIO_DABL_NOX ? make_float4(0.5f, 0.25f, 1.f, 2.f) : *(const float4*)(xp + 16 * (HC + c));
+    for (int c = 0; c < HC; ++c) xb[c] = *(const float4*)(xp + 16 * (HC + c));
     }
     __builtin_amdgcn_sched_barrier(0);
     f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = (f32x4){0.f, 0.f, 0.f, 0.f};   // two independent MFMA chains
@@ -296,7 +274,6 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? PIO_DEC_GEMM_WAVES : 1) void k
 #pragma unroll
     for (int cc = 0; cc < CPW; cc += 2) {
       const float4 x0 = PIO_XC(cc), x1 = PIO_XC(cc + 1);
-      if (PIO_DABL_NOMFMA == 1 && cc >= CPW / 6) { a0[0] += x0.x * w4[cc].x + x0.w * w4[cc].w; a1[0] += x1.x * w4[cc + 1].x + x1.w * w4[cc + 1].w; continue; }
       a0 = mfma16f(x0.x, w4[cc].x, a0);  a1 = mfma16f(x1.x, w4[cc + 1].x, a1);
       a0 = mfma16f(x0.y, w4[cc].y, a0);  a1 = mfma16f(x1.y, w4[cc + 1].y, a1);
       a0 = mfma16f(x0.z, w4[cc].z, a0);  a1 = mfma16f(x1.z, w4[cc + 1].z, a1);
@@ -342,39 +319,27 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? PIO_DEC_GEMM_WAVES : 1) void k
       const int g = wid + NWV * gi;
       if (g < RG) {
         float* sp = slab + ((size_t)blockIdx.y * RG + g) * 256 + lane * 4;
-        if constexpr (PIO_DEC_LEAN_TICKET) st_agent(sp, sums[gi]);
-        else *(f32x4*)sp = sums[gi];
+        st_agent(sp, sums[gi]);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its stores
     __syncthreads();
     if (tid == 0) {
-      if constexpr (!PIO_DEC_LEAN_TICKET) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the release's write-back has completed
-      }
       const unsigned t = __hip_atomic_fetch_add(cnt + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_last = (t == (unsigned)(KS - 1));
     }
     __syncthreads();
     PIO_STAMP(5);
     if (!s_last) return;
-    if (tid == 0) {
-      if constexpr (!PIO_DEC_LEAN_TICKET) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __hip_atomic_store(cnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
-    }
-    if constexpr (!PIO_DEC_LEAN_TICKET) __syncthreads();
+    if (tid == 0) __hip_atomic_store(cnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
 #pragma unroll
     for (int gi = 0; gi < (RG + NWV - 1) / NWV; ++gi) {
       const int g = wid + NWV * gi;
       if (g < RG) {
         const float* sp = slab + (size_t)g * 256 + lane * 4;
-        f32x4 s = PIO_DEC_LEAN_TICKET ? ld_agent(sp) : *(const f32x4*)sp;
+        f32x4 s = ld_agent(sp);
 #pragma unroll
-        for (int y = 1; y < KS; ++y) s += PIO_DEC_LEAN_TICKET ? ld_agent(sp + (size_t)y * RG * 256) : *(const f32x4*)(sp + (size_t)y * RG * 256);
+        for (int y = 1; y < KS; ++y) s += ld_agent(sp + (size_t)y * RG * 256);
         sums[gi] = s;
       }
     }
@@ -751,7 +716,6 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_b(const float* __rest
     const float* _xb = lsm + ((q) % RB) * XB;                                                                  \
     _Pragma("unroll") for (int g = 0; g < RGB; ++g) {                                                          \
       const float4 xf = *(const float4*)(_xb + (16 * g + li) * CH + (((4 * kw + kq) ^ li) << 2));              \
-      if (PIO_DABL_NOMFMA == 1 && (q) >= 2) { acc[g][0] += xf.x * w[q][0] + xf.w * w[q][3]; continue; }             \
       acc[g] = mfma16f(xf.x, w[q][0], acc[g]);                                                                 \
       acc[g] = mfma16f(xf.y, w[q][1], acc[g]);                                                                 \
       acc[g] = mfma16f(xf.z, w[q][2], acc[g]);                                                                 \
@@ -799,34 +763,22 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_b(const float* __rest
     const int pr = cg * RGB + g;
     if (fin) {
       float* sp = tbase + ((size_t)blockIdx.y * NP + pr) * 256 + lane * 4;
-      if constexpr (PIO_DEC_LEAN_TICKET) st_agent(sp, s);
-      else *(f32x4*)sp = s;
+      st_agent(sp, s);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its stores
     __syncthreads();
     if (tid == 0) {
-      if constexpr (!PIO_DEC_LEAN_TICKET) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the release's write-back has completed
-      }
       const unsigned t = __hip_atomic_fetch_add(cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_last = (t == (unsigned)(KS - 1));
     }
     __syncthreads();
     if (!s_last) return;
-    if (tid == 0) {
-      if constexpr (!PIO_DEC_LEAN_TICKET) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __hip_atomic_store(cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
-    }
-    if constexpr (!PIO_DEC_LEAN_TICKET) __syncthreads();
+    if (tid == 0) __hip_atomic_store(cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
     if (fin) {
       const float* sp = tbase + (size_t)pr * 256 + lane * 4;
-      s = PIO_DEC_LEAN_TICKET ? ld_agent(sp) : *(const f32x4*)sp;
+      s = ld_agent(sp);
 #pragma unroll
-      for (int y = 1; y < KS; ++y) s += PIO_DEC_LEAN_TICKET ? ld_agent(sp + (size_t)y * NP * 256) : *(const f32x4*)(sp + (size_t)y * NP * 256);
+      for (int y = 1; y < KS; ++y) s += ld_agent(sp + (size_t)y * NP * 256);
     }
   }
   if (!fin) return;
@@ -871,7 +823,7 @@ static hipError_t dec_gemm_b_launch(const float* W, const float* X, int N, int N
   return hipGetLastError();
 }
 
-// ---- layer GEMMs above 16 prefixes on split-fp16 operands (PIO_DEC_SPLIT) ------------------------------------------------
+// ---- layer GEMMs above 64 prefixes (PIO_DEC_SPLIT_MIN_RG = 5 row groups of 16) on split-fp16 operands (PIO_DEC_SPLIT) ------------------------------------------------
 // The fp32 MFMA (v_mfma_f32_16x16x4_f32: 256 flop / clk / CU) is what a k_dec_gemm_b workgroup spends its residency on at 64+
 // prefixes (tools/microbench: a quarter of the pipe time = -15 % of a 128-prefix decode).  Here both operands are pairs of fp16
 // numbers, x S = hi + lo' 2^-11 with hi = fp16(x S) and lo' = fp16((x S - hi) 2^11) -- 22 bits of the 24, the low half kept in the
@@ -918,7 +870,7 @@ hipError_t dec_split_weights(const float* W, size_t n, void* out, float* unscale
   if (e == hipSuccess) { hipLaunchKernelGGL(k_dec_abs_max, dim3(512), dim3(256), 0, s, W, n, d); e = hipGetLastError(); }
   if (e == hipSuccess) e = hipMemcpyAsync(&bits, d, 4, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  hipFree(d);
+  (void)hipFree(d);
   if (e != hipSuccess) return e;
   float amax;
   memcpy(&amax, &bits, 4);
@@ -939,17 +891,16 @@ hipError_t launch_dec_split_weights(const float* W, size_t n, float S, void* out
 
 // x (4 floats) -> hi = fp16 toward zero, lo' = fp16((x - hi) 2^11): x 2^11 - hi 2^11 is exact in one FMA (hi is x cut to 11 bits), and the
 // hi operand rides in as fp16 (v_fma_mix_f32): a multiply and an FMA per element instead of convert, subtract, multiply.
+// lo' is rounded to NEAREST (v_cvt_pk_f16_f32; round 5): cut toward zero like hi it shrank every activation by up to 2^-21 of
+// itself, always in the same direction, where the weights' split (round-to-nearest, k_dec_split_weights) has no such bias; now
+// |x - (hi + lo' 2^-11)| <= 2^-22 |x| and the error has no sign.  hi stays cut: v_cvt_pkrtz saturates, which the range bookkeeping below relies on.
 __device__ __forceinline__ void dec_split4(const float4 x, const float s, dec_h4& hi, dec_h4& lo) {
-#if PIO_DABL_NOSPLIT       // timing ablation: the staging without its arithmetic (what planes written by the PRODUCERS would leave); wrong results
-  hi = __builtin_bit_cast(dec_h4, make_float2(x.x, x.y));
-  lo = __builtin_bit_cast(dec_h4, make_float2(x.z, x.w));
-  return;
-#endif
   const float v0 = x.x * s, v1 = x.y * s, v2 = x.z * s, v3 = x.w * s;
   const dec_h2 h01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v0, v1)), h23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(v2, v3));
   const float l0 = __builtin_fmaf((float)h01[0], -2048.0f, v0 * 2048.0f), l1 = __builtin_fmaf((float)h01[1], -2048.0f, v1 * 2048.0f);
   const float l2 = __builtin_fmaf((float)h23[0], -2048.0f, v2 * 2048.0f), l3 = __builtin_fmaf((float)h23[1], -2048.0f, v3 * 2048.0f);
-  const dec_h2 l01 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(l0, l1)), l23 = __builtin_bit_cast(dec_h2, __builtin_amdgcn_cvt_pkrtz(l2, l3));
+  typedef float dec_f2 __attribute__((ext_vector_type(2)));
+  const dec_h2 l01 = __builtin_convertvector((dec_f2){l0, l1}, dec_h2), l23 = __builtin_convertvector((dec_f2){l2, l3}, dec_h2);
   hi = (dec_h4){h01[0], h01[1], h23[0], h23[1]};
   lo = (dec_h4){l01[0], l01[1], l23[0], l23[1]};
 }
@@ -1023,7 +974,6 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
       const int row = wid + NW * i;
       if (row < ROWS) {
         float sx = 0.f, sq = 0.f;
-        const float x_dummy = 1.0f;
         dec_h2 ra2 = (dec_h2){(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
@@ -1034,18 +984,14 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
           *(dec_h4*)d = hi;
           *(dec_h4*)(d + PLANE) = lo;
           ra2 = dec_absmax4(hi, ra2);
-          if (!PIO_DABL_NOSPLIT) {
-            sx += (x.x + x.y) + (x.z + x.w);
-            sq += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
-          }
+          sx += (x.x + x.y) + (x.z + x.w);
+          sq += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
         }
         const float ra = fmaxf((float)ra2[0], (float)ra2[1]);
         am = fmaxf(am, ra);
         small |= __builtin_amdgcn_ballot_w64(ra >= 0.0009765625f) == 0ull && __builtin_amdgcn_ballot_w64(ra > 0.f) != 0ull;   // per ROW here
-        if (!PIO_DABL_NOSPLIT) {
-          sx = wave_sum_dpp(sx);
-          sq = wave_sum_dpp(sq);
-        } else { sx = x_dummy; sq = 768.f; }
+        sx = wave_sum_dpp(sx);
+        sq = wave_sum_dpp(sq);
         if (lane == 0) { s_sum[row][0] = sx; s_sum[row][1] = 0.f; s_sum[row][2] = 0.f; s_sq[row][0] = sq; s_sq[row][1] = 0.f; s_sq[row][2] = 0.f; }
       }
     }
@@ -1086,11 +1032,6 @@ __global__ __launch_bounds__(256 * NCG, 1) void k_dec_gemm_s(const u32x4_t* __re
       // (2^-10: see above; fc2 / proj add into the residual stream, where the ABSOLUTE error counts and is 2^-35 whatever the row's size, so a
       //  "small" chunk only costs them the careful path)
       small |= __builtin_amdgcn_ballot_w64(a4 >= 0.0009765625f) == 0ull && __builtin_amdgcn_ballot_w64(a4 > 0.f) != 0ull;
-      if (LN) {
-        const float sx = wave_sum_dpp((x.x + x.y) + (x.z + x.w));
-        const float sq = wave_sum_dpp((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w));
-        if (lane == 0) { s_sum[row][part] = sx; s_sq[row][part] = sq; }
-      }
     }
   }
   }
@@ -1284,13 +1225,6 @@ static hipError_t dec_gemm(const float* W, const float* X, int N, int Nout, int 
     const int rg = ceil_div(N, 16);
     if (rg >= 2 && K == 768 && Nout % 48 == 0) {
       const bool wide = Nout >= 2304;       // qkv / fc: 48 (32) columns per workgroup; proj: 16
-#if PIO_DEC_DENSE == 1
-      if (rg > 4) return wide ? dec_gemm_b_launch<4, 4, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s)
-                              : dec_gemm_b_launch<4, 1, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
-#elif PIO_DEC_DENSE == 2
-      if (rg > 4) return wide ? dec_gemm_b_launch<4, 2, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s)
-                              : dec_gemm_b_launch<4, 1, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
-#endif
       if (rg > 4) return wide ? dec_gemm_b_launch<2, 3, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s)
                               : dec_gemm_b_launch<2, 1, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s);
       if (rg > 2) return wide ? dec_gemm_b_launch<2, 2, 1, EPI, LN>(W, X, N, Nout, K, bias, out, cvec, eps, ws, cnt, s)
@@ -1576,7 +1510,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_lmhead_f16(const
 #define PIO_XISSUE(q, buf)                                                                                     \
   do {                                                                                                         \
     _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                          \
-      if (PIO_LMF16_ABL != 2 && (NP % NWV == 0 || wid + NWV * i < NP)) {                                           \
+      if (NP % NWV == 0 || wid + NWV * i < NP) {                                           \
         const char* _g = (const char*)Xh + (q) * (CH * 2) + xoff[i];                                           \
         const uint32_t _l = lds0 + (uint32_t)((buf) * XB + i * NWV * 1024);                                          \
         uint32_t _keep;                                                                                        \
@@ -1620,8 +1554,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_lmhead_f16(const
         const int row = 16 * g + li;                                                                           \
         const dec_h8 xf = *(const dec_h8*)(xb + row * 128 + (((4 * c + kq) ^ ((row >> 1) & 7)) << 4));         \
         _Pragma("unroll") for (int cgi = 0; cgi < CPW; ++cgi) {                                                \
-          if (PIO_LMF16_ABL == 3) acc[cgi][g][0] += (float)xf[0] * w[set][2 * cgi + c][0];                    \
-          else acc[cgi][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, __builtin_bit_cast(dec_h8, w[set][2 * cgi + c]), acc[cgi][g], 0, 0, 0); \
+          acc[cgi][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, __builtin_bit_cast(dec_h8, w[set][2 * cgi + c]), acc[cgi][g], 0, 0, 0); \
         }                                                                                                      \
       }                                                                                                        \
     }                                                                                                          \
@@ -1675,13 +1608,6 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_lmhead_f16(const
     const int blk = blk0 + cgi, j = blk * 16 + li, jc = j < V ? j : V - 1;
     if (blk * 16 >= V) break;                         // wave-uniform: no columns
     const float cj = cvec[jc], dj = dvec[jc];
-    if (PIO_LMF16_ABL == 1) {
-      float t = 0.f;
-#pragma unroll
-      for (int g = 0; g < RG; ++g) t += acc[cgi][g][0] + acc[cgi][g][1] + acc[cgi][g][2] + acc[cgi][g][3];
-      if (t == 12345.678f) out[j] = t;
-      continue;
-    }
 #pragma unroll
     for (int g = 0; g < RG; ++g)
 #pragma unroll

@@ -27,6 +27,8 @@ from typing import Iterable, Iterator, List, Optional, Sequence, Tuple
 
 import torch
 
+import patchioner_amd as _pkg
+
 
 # CU-masked streams (pio_stream_create) live for the life of the PROCESS, like torch's own pooled streams: torch's caching
 # allocators -- device blocks with record_stream'ed uses, pinned host blocks used by a non-blocking copy -- keep the raw
@@ -178,7 +180,10 @@ class TraceCaptionPipeline:
             import sys
             print("patchioner_amd.pipeline: %d of %d decode streams run beside the stage stream(s); %d share a hardware queue "
                   "(probe ratios %s, one spin %.3f ms)%s" % (len(chosen), n, max(0, n - len(chosen)), ratios, base * 1e3,
-                  "" if len(chosen) == n else " -- set GPU_MAX_HW_QUEUES=8 or use fewer decode clones"), file=sys.stderr)
+                  "" if len(chosen) == n else " -- use fewer decode clones, or start the process with GPU_MAX_HW_QUEUES=8 (HIP reads it "
+                  "once, at its first GPU call: %s)" % ("this process had initialised the GPU before patchioner_amd was imported, so the "
+                                                        "package's default of 8 came too late" if _pkg._HIP_UP_AT_IMPORT else
+                                                        "effective value here: %s" % os.environ.get("GPU_MAX_HW_QUEUES"))), file=sys.stderr)
         return chosen + spare[:n - len(chosen)]               # not enough independent queues: take what there is
 
     def _make_stream(self, n_cus, from_top: bool = False, priority: int = 0):

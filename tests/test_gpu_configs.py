@@ -420,20 +420,23 @@ def test_argmax_text_and_n_best_sims_from_the_h5_bank(O):
         _model(224, True, max_batch=2)(imgs, return_n_best_sims=2)    # not a calculate_argmax_text model
 
 
-def test_vit_80_images_per_launch_rolling_gemm_is_bitwise_the_16_image_launches():
-    """One ViT launch of 80 images sends qkv / fc1 (747 / 996 tiles of 256^2) to the persistent kernel with the rolling
-    epilogue (vit_gemm_roll.hip) and proj / fc2 to k_vit_gemm256; 16-image launches use the 128- and 256-tile kernels.
-    Every kernel computes an output element with the same arithmetic, so the tokens and the captured qkv are the same BITS
-    whatever a launch holds -- the property the pipeline's shared ViT launches rely on.  Depth 3: middle blocks (rolling
-    qkv) and the last block (qkv with the fp32 capture, the 256 kernel)."""
+@pytest.mark.parametrize("n_big", [80, 160])
+def test_vit_80_images_per_launch_rolling_gemm_is_bitwise_the_16_image_launches(n_big):
+    """One ViT launch of 80 (160) images sends qkv / fc1 (747 / 996 tiles of 256^2; twice that at 160) and -- round 5 -- proj / fc2
+    (249 tiles = one per workgroup; 495 = two at 160, so the second tile's multiplies run beside the first one's stores) to the
+    persistent kernel with the rolling epilogue (vit_gemm_roll.hip); 16-image launches use the 128- and 256-tile kernels.  Every kernel
+    computes an output element with the same arithmetic -- for proj / fc2 that includes WHEN the old residual value joins the sum
+    (kernels.h: resid_join_ktile) -- so the tokens and the captured qkv are the same BITS whatever a launch holds: the property the
+    pipeline's shared ViT launches rely on.  Depth 3: middle blocks (rolling qkv) and the last block (qkv with the fp32 capture, the 256
+    kernel)."""
     from patchioner_amd.engine import Engine
     sd = W.synth_dinov2(17, depth=3)
-    big = Engine(embed_dim=768, depth=3, num_heads=12, num_registers=4, crop_dim=224, max_batch=80, vit_dtype="fp16")
+    big = Engine(embed_dim=768, depth=3, num_heads=12, num_registers=4, crop_dim=224, max_batch=n_big, vit_dtype="fp16")
     small = Engine(embed_dim=768, depth=3, num_heads=12, num_registers=4, crop_dim=224, max_batch=16, vit_dtype="fp16")
     for e in (big, small):
         e.load_state_dict(sd)
         e.finalize()
-    imgs = W.synth_images(5, 80, 224).cuda()
+    imgs = W.synth_images(5, n_big, 224).cuda()
     tok_b, qkv_b = big.vit_forward(imgs)
     tok_s, qkv_s = small.vit_forward(imgs)
     torch.cuda.synchronize()
@@ -442,6 +445,36 @@ def test_vit_80_images_per_launch_rolling_gemm_is_bitwise_the_16_image_launches(
     tok_b2, _ = big.vit_forward(imgs)                 # and the same bits again (a race would not reproduce)
     assert torch.equal(tok_b, tok_b2)
     big.close(); small.close()
+
+
+def test_residual_gemm_takes_layerscale_folded_and_any_magnitude():
+    """proj / fc2 multiply by W' = op(ls W) (LayerScale folded at load, api.cpp) and take the old x into the sum as one of its terms.
+    Against the oracle's fp32 blocks at depth 2 with LayerScale vectors spread over six orders of magnitude (1e-5, the DINOv2
+    initial value, to 3; some negative), ragged 518^2 rows and a batch that takes the 128-wide kernels: the tokens hold the ViT
+    tolerance, i.e. folding gamma into fp16 weights (subnormal for the smallest) loses nothing that matters at the residual's scale."""
+    from oracle import patchioner_oracle as O
+    from patchioner_amd.engine import Engine
+    for crop, B in ((224, 3), (518, 2)):
+        sd = W.synth_dinov2(29, depth=2)
+        g = torch.Generator().manual_seed(31)
+        for l in range(2):
+            for k in ("ls1", "ls2"):
+                e = torch.rand(768, generator=g) * 5.5 - 5.0                     # 1e-5 .. 3
+                sign = torch.where(torch.rand(768, generator=g) < 0.2, -1.0, 1.0)
+                sd["blocks.%d.%s.gamma" % (l, k)] = (10.0 ** e) * sign
+        eng = Engine(embed_dim=768, depth=2, num_heads=12, num_registers=4, crop_dim=crop, max_batch=B, vit_dtype="fp16")
+        try:
+            eng.load_state_dict(sd)
+            eng.finalize()
+            imgs = W.synth_images(37, B, crop)
+            tokens, _ = eng.vit_forward(imgs)
+            d = O.DinoV2Oracle(sd, num_heads=12)(imgs)
+            ref = torch.cat([d["x_norm_clstoken"][:, None], d["x_norm_regtokens"], d["x_norm_patchtokens"]], 1)
+            err = float((tokens.cpu() - ref).abs().max() / ref.abs().max())
+            print("LayerScale over six orders of magnitude at %d^2: rel-max-err %.2e" % (crop, err))
+            assert err <= 4e-3
+        finally:
+            eng.close()
 
 
 def test_clip_vit_backbone_decap_original_config(O):

@@ -364,9 +364,9 @@ def test_decoder_128_prefixes_in_one_call(golden):
 
 
 def test_decoder_split_fp16_layer_gemms_take_any_finite_prefix(golden):
-    """Above 64 prefixes the layer GEMMs run on split-fp16 operands (decoder.hip: k_dec_gemm_s): activations are scaled by a fixed
-    2^-4 before the split, and a workgroup that sees magnitudes beyond fp16's range stages its slice again with a scale chosen from
-    the maximum.  Rows scaled by 1e-6 ... 1e8 (the fp32 kernels take any finite prefix) decode to the ids the SAME rows give in
+    """Above 64 prefixes the layer GEMMs run on split-fp16 operands (decoder.hip: k_dec_gemm_s): activations are split as they are
+    (no pre-scale: DEC_SPLIT_XS = 1), and a workgroup that sees a row outside fp16's comfortable range stages its slice again, every
+    row with its own power-of-two scale.  Rows scaled by 1e-6 ... 1e8 (the fp32 kernels take any finite prefix) decode to the ids the SAME rows give in
     calls of 16, which run the fp32 kernels; 96 rows = three 32-row blocks, each holding small and huge rows side by side."""
     from patchioner_amd.engine import Engine
     e = Engine(embed_dim=768, depth=1, num_heads=12, num_registers=4, crop_dim=224, max_batch=2, max_prefixes=128, vit_dtype="fp16")

@@ -3,7 +3,7 @@
 #   tools/microbench/bench_sweep.sh  ->  gpurun_out/sweep.log  (one line per setting: captions/s, median ms per group)
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
-export PIO_BENCH_STAT_GROUPS=24 PIO_BENCH_SYNC_STEPS=4
+export PIO_BENCH_NO_160=1 PIO_BENCH_STAT_GROUPS=24 PIO_BENCH_SYNC_STEPS=4
 run() {   # label, env assignments..., -- bench args...
   local label=$1; shift
   local envs=()
