@@ -54,6 +54,9 @@ namespace pio {
 #ifndef PIO_ATTN_PLAIN_VALU   // 1: the softmax's FMAs / adds as plain VALU instructions (see the kernel)
 #define PIO_ATTN_PLAIN_VALU 1
 #endif
+#ifndef PIO_ATTN_VSWZ_PARITY  // 1: the V^T staging image's swizzle includes the row's parity (round 5; 0 = rounds 2-4, for the A/B build)
+#define PIO_ATTN_VSWZ_PARITY 1
+#endif
 #ifndef PIO_ATTN_OCC          // waves per SIMD k_vit_attention is compiled for: 2 (144 VGPRs, three workgroups per CU in practice);
 #define PIO_ATTN_OCC 2         // 4 = 128 VGPRs with 56 B of scratch, measured: see the file header
 #endif
@@ -120,8 +123,14 @@ __global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAt
   for (int i = 0; i < 2; ++i) {
     const int row = row0 + 32 * i, swz = (row >> 1) & 7;
     lds_off[i] = row * 128 + ((kc ^ swz) << 4);
-    lds_off_v[i][0] = row * 128 + ((((kc & ~1) + 0) ^ swz) << 4) + (kc & 1) * 8;
-    lds_off_v[i][1] = row * 128 + ((((kc & ~1) + 1) ^ swz) << 4) + (kc & 1) * 8;
+    // (round 5) ... XORed with the row's parity as well: a ds_write_b64 is served in groups of 16 lanes = two neighbouring rows, which
+    // share (row >> 1) & 7 and -- 128 B apart -- the same banks: both wrote slots {j, 2 + j, 4 + j, 6 + j} and every such store took two
+    // passes (SQ_LDS_BANK_CONFLICT 0.18 of the LDS cycles for three rounds: four of these stores per thread and tile against 16 fragment
+    // reads per wave).  Now the odd row writes the other four slots.  The fragment reads stay conflict-free: a read group's even and odd
+    // rows sit in different bank halves, and inside each half the extra XOR is the same for every lane.
+    const int swv = swz ^ (PIO_ATTN_VSWZ_PARITY ? (row & 1) : 0);
+    lds_off_v[i][0] = row * 128 + ((((kc & ~1) + 0) ^ swv) << 4) + (kc & 1) * 8;
+    lds_off_v[i][1] = row * 128 + ((((kc & ~1) + 1) ^ swv) << 4) + (kc & 1) * 8;
   }
   // staging registers: plain named values (arrays captured by lambdas end up in scratch)
   uint4 rk0, rk1, rv0, rv1;
@@ -149,6 +158,7 @@ __global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAt
   } while (0)
 
   const int sw7 = (lane >> 1) & 7;
+  const int sw7v = sw7 ^ (PIO_ATTN_VSWZ_PARITY ? (lane & 1) : 0);              // V^T rows: the staging's swizzle includes the row's parity (lds_off_v)
   const float sl2 = a.scale * 1.44269504088896340736f;  // softmax in the log2 domain
   float m_run = -1e30f, l_run = 0.f;
   f32x16 ot[2];
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAt
           frag_t pf;                                                                                                  \
           _Pragma("unroll") for (int j = 0; j < 4; ++j) { pf[2 * j] = ph[kbk][4 * s2 + j][0]; pf[2 * j + 1] = ph[kbk][4 * s2 + j][1]; } \
           _Pragma("unroll") for (int d = 0; d < 2; ++d) {                                                             \
-            const frag_t vf = *(const frag_t*)(sv + (d * 32 + r31) * 128 + (((4 * kbk + 2 * s2 + h) ^ sw7) << 4));    \
+            const frag_t vf = *(const frag_t*)(sv + (d * 32 + r31) * 128 + (((4 * kbk + 2 * s2 + h) ^ sw7v) << 4));   \
             ot[d] = mfma32(vf, pf, ot[d]);                                                                            \
           }                                                                                                           \
         }                                                                                                             \

@@ -113,35 +113,66 @@ __global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? PIO_GEMM_WIDE_OCC
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // EPI_RESIDUAL (kernels.h: resid_join_ktile): the old x of this wave's elements, loaded up front (32 registers per 32-row block: this
-  // kernel has them to spare) and added to the running sums after the K-tile the canonical order names.  A 32 x 32 block of a wave lies
-  // inside one unit of the 256-grid, so the K-tile is wave-uniform per block.
+  // kernel has them to spare) and added to the running sums after the K-tile the canonical order names: class u = row mod 8 = 4 h + (r & 3)
+  // (a block of 32 rows starts at a multiple of 32), i.e. after K-tile J(u) the lanes of half u >> 2 add their registers r = u (mod 4).
   const int nk = g.K / BK;                  // even and >= 2 (checked by the launcher)
-  float xin[EPI == EPI_RESIDUAL ? MI : 1][2][16];
-  int xjoin[MI];
-  if constexpr (EPI == EPI_RESIDUAL) {
+  // Two forms.  NBUF == 3 (64-row tiles): all of the wave's x up front, 32 registers.  NBUF < 3 (128-row tiles; every barrier there
+  // follows an s_waitcnt vmcnt(0), PIO_LANDED): one class at a time, fetched a K-tile before it joins -- holding 64 registers of x
+  // beside 64 of sums spilled into the main loop (round 5).  The one-class buffer needs every class on a K-tile of its own: nk >= 10
+  // (launcher).
+  constexpr bool XLAZY = EPI == EPI_RESIDUAL && NBUF != 3;
+  float xin[EPI == EPI_RESIDUAL && !XLAZY ? MI : 1][2][16];
+  float xlz[XLAZY ? MI : 1][2][4];
+  int xjk[4] = {0, 0, 0, 0};               // per lane: the K-tile after which its registers r = c (mod 4) take their x in
+#define PIO_X_INDEX(i, j, r) ((uint32_t)min(m0 + wm * (BM / 2) + (i) * 32 + acc_row32((r), lane), g.M - 1) * (uint32_t)g.N + \
+                             (uint32_t)(n0 + wn * 64 + (j) * 32 + r31))      /* rows past M: a copy of the last row, never stored; M N < 2^30 (launcher) */
+  if constexpr (EPI == EPI_RESIDUAL && !XLAZY) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int mb = m0 + wm * (BM / 2) + i * 32;
-      xjoin[i] = resid_join_ktile(resid_unit(mb, n0), nk);
+    for (int c = 0; c < 4; ++c) xjk[c] = resid_join_ktile(4 * h + c, nk);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + acc_row32(r, lane);
-          xin[i][j][r] = m < g.M ? g.x[(size_t)m * g.N + n0 + wn * 64 + j * 32 + r31] : 0.f;
-        }
-    }
+        for (int r = 0; r < 16; ++r) xin[i][j][r] = g.x[PIO_X_INDEX(i, j, r)];
   }
+  // the class that joins after K-tile ktn, into the one-class buffer (lazy form): u = ktn - 1 is scalar, so ONE block of loads
+  // serves every class (the rows 8 gq + 4 h + (u & 3) of a 32-row block); the adds need the register index at compile time
+#define PIO_FETCH_X(ktn)                                                                               \
+  do {                                                                                                 \
+    if constexpr (XLAZY) {                                                                             \
+      const int _u = (ktn) - 1;                                                                        \
+      if (_u >= 0 && _u < 8 && h == (_u >> 2)) {                                                       \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)   \
+          _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                           \
+            const int _m = min(m0 + wm * (BM / 2) + i * 32 + 8 * gq + 4 * h + (_u & 3), g.M - 1);      \
+            xlz[i][j][gq] = g.x[(uint32_t)_m * (uint32_t)g.N + (uint32_t)(n0 + wn * 64 + j * 32 + r31)]; \
+          }                                                                                            \
+      }                                                                                                \
+    }                                                                                                  \
+  } while (0)
 #define PIO_JOIN_X(kt)                                                                                 \
   do {                                                                                                 \
-    if constexpr (EPI == EPI_RESIDUAL) {                                                               \
-      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
-        if ((kt) == xjoin[i]) {                                                                        \
-          _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r) \
-            acc[i][j][r] += xin[i][j][r];                                                              \
+    if constexpr (XLAZY) {                                                                             \
+      const int _u = (kt) - 1;                                                                         \
+      if (_u >= 0 && _u < 8 && h == (_u >> 2)) {                                                       \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                  \
+          if ((_u & 3) == c) {                                                                         \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+              _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) acc[i][j][4 * gq + c] += xlz[i][j][gq]; \
+          }                                                                                            \
+      }                                                                                                \
+      PIO_FETCH_X((kt) + 1);                                                                           \
+    } else if constexpr (EPI == EPI_RESIDUAL) {                                                        \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                    \
+        if (xjk[c] == (kt)) {                    /* per lane half: skipped when no lane of the wave joins here */ \
+          _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+            _Pragma("unroll") for (int gq = 0; gq < 4; ++gq)                                           \
+              acc[i][j][4 * gq + c] += xin[i][j][4 * gq + c];                                          \
         }                                                                                              \
     }                                                                                                  \
   } while (0)
+  PIO_FETCH_X(1);
 
 #define PIO_ISSUE_TILE(kt, buf)                                                                        \
   do {                                                                                                 \
@@ -243,6 +274,8 @@ __global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? PIO_GEMM_WIDE_OCC
 #undef PIO_ISSUE_TILE
 #undef PIO_COMPUTE_TILE
 #undef PIO_JOIN_X
+#undef PIO_FETCH_X
+#undef PIO_X_INDEX
 #undef PIO_LANDED
 
   // ---- epilogue: accumulators -> LDS [64][128] fp32 (one 32-row MFMA tile row of each wave per pass) ->
@@ -396,7 +429,7 @@ static hipError_t launch_typed(GemmEpilogue epi, const GemmArgs& a, hipStream_t 
       // element, so the result does not depend on the tile height.
       {
         static const int force_bm = [] { const char* e = getenv("PIO_GEMM_RES_BM"); return e ? atoi(e) : 0; }();   // diagnostic: 64 / 128
-        if (force_bm == 128 || (force_bm == 0 && ceil_div(a.M, 128) * (a.N / BN) >= 384)) return launch_one<T, EPI_RESIDUAL, 128, 2>(a, s);
+        if (a.K / BK >= 10 && (force_bm == 128 || (force_bm == 0 && ceil_div(a.M, 128) * (a.N / BN) >= 384))) return launch_one<T, EPI_RESIDUAL, 128, 2>(a, s);
       }
       return launch_one<T, EPI_RESIDUAL, PIO_GEMM_BM_NARROW, PIO_GEMM_NBUF_NARROW>(a, s);
     case EPI_GELU:
@@ -459,6 +492,7 @@ hipError_t launch_vit_gemm(OperandType t, GemmEpilogue epi, const GemmArgs& a, h
   if (a.M <= 0 || a.N % BN != 0 || a.K % (2 * BK) != 0 || a.lda % 8 != 0) return hipErrorInvalidValue;
   // the staging offsets are 32-bit byte offsets from A and W
   if ((size_t)a.M * a.lda * 2 >= ((size_t)1 << 32) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
+  if (epi == EPI_RESIDUAL && (size_t)a.M * a.N >= ((size_t)1 << 30)) return hipErrorInvalidValue;      // 32-bit element index into x
   return t == OP_F16 ? launch_typed<f16>(epi, a, s) : launch_typed<bf16>(epi, a, s);
 }
 

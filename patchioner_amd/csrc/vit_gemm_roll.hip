@@ -40,18 +40,19 @@
 // per element of traffic where q / k / fc1 outputs are 2, and in k_vit_gemm256 that read-modify-write was all exposed (proj: 31.6 k of a
 // tile's 62.8 k cycles).  Here neither half of it waits for the other or for the multiplies:
 //   * READ: the old x JOINS the running sum in the middle of the main loop (kernels.h, resid_join_ktile: one definition of the order for
-//     every GEMM kernel).  The accumulator is eight units of (quadrant, 32-row half); unit u's 32 x 32 patch per wave (4 KiB) is fetched
-//     by four LDS-DMA pieces into the wave's OWN 4 KiB of the staging image during K-tile u + 1 (issued after that K-tile's counted wait,
-//     so the next K-tile's wait retires it: every vmcnt keeps its meaning), read back in accumulator order in K-tile u + 2 -- the DMA
-//     deposits with the main ring's swizzle, so those reads are the conflict-free fragment pattern -- and added (16 VALU per wave).
-//   * WRITE: the finished units leave one per interval in the last K-tile and the next tile's first one: bias (SGPRs), four ds_write_b128
-//     in accumulator order into the same 4 KiB, four lane-linear ds_read_b128 (rows of 128 B), four 16-B buffer stores to the addresses
-//     the unit's x came from.  Everything a wave stages it reads back itself: no barrier, no cross-wave hazard; LDS operations of one
+//     every GEMM kernel, keyed to the row's index mod 8 so that it does not depend on where an image sits in a launch).  One row class
+//     per K-tile: the wave's 32 rows of the class x its 32 columns of both tile halves (4 KiB) are fetched by four LDS-DMA pieces into
+//     the wave's OWN 4 KiB of the staging image (issued behind a K-tile's counted wait, so the next K-tile's wait retires them: every
+//     vmcnt keeps its meaning), read back a K-tile later and added by the lane half that holds the class (32 VALU per wave).
+//   * WRITE: the finished 32 x 32 blocks leave one per interval in the last K-tile and the next tile's first one: bias (a VGPR: the
+//     column is the lane), 16 ds_write_b32 into the same 4 KiB as a row-major image, four lane-linear ds_read_b128, four 16-B buffer
+//     stores of 8 rows x 128 B.  Everything a wave stages it reads back itself: no barrier, no cross-wave hazard; LDS operations of one
 //     wave execute in order, so a unit's reads precede the next unit's writes without a wait.
-//   Unit slots (u = 2 q + rt; L = last K-tile, F = first of the next tile; waves 0-3 run hooks after an interval's MFMAs, waves 4-7 before):
+//   Output slots (u = 2 q + rt; L = last K-tile, F = first of the next tile; waves 0-3 run hooks after an interval's MFMAs, waves 4-7 before):
 //       waves 0-3:  L0 u0  L1 u1  L2 u2  L3 u3  F0 u4  F1 u5  F2 u6  F3 (before its MFMAs) u7
 //       waves 4-7:  L1 u0  L2 u1  L3 u2  F0 u3  F1 u4  F2 u5  F3 (before its MFMAs) u6, u7
-//   a unit is final after interval L(q) and its registers restart from zero in F(q): every slot lies between the two.
+//   a block is final after interval L(q) and its registers restart from zero in F(q): every slot lies between the two.
+//   What it buys (tools/microbench/gemm256_bench, profiles/r05_*): see DESIGN.md section 5, round 5.
 #include "common.h"
 #include "kernels.h"
 
@@ -70,7 +71,7 @@ __device__ unsigned long long* roll_stamps = nullptr;
 #ifndef PIO_ROLL_GELU_PACKED     // GELU in the hooks on packed fp32 (fewer issue cycles, no overlap with MFMAs) or plain VALU
 #define PIO_ROLL_GELU_PACKED 0   // measured: no difference (fc1 at 80 images 123.9 vs 122.9 us; last K-tile 13.1 k vs 12.6 k cycles)
 #endif
-#ifndef PIO_ROLL_ABL             // diagnostic ablations (bit 0: bias = 0 without its scalar loads; bit 1: E3 without its global stores)
+#ifndef PIO_ROLL_ABL             // diagnostic ablations (bit 0: bias = 0 without its scalar loads; bit 1: E3 without its global stores; bit 2: no residual bias load; bit 3: no x-in DMA)
 #define PIO_ROLL_ABL 0
 #endif
 
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
   // quadrants in phase order: 0 = (A0,B0), 1 = (A0,B1), 2 = (A1,B1), 3 = (A1,B0); [row tile rt].  Token on the lane:
   // acc[q][rt][4a+e] = C[m0 + 128 I + 64 wr + 32 rt + r31][n0 + 128 J + 32 wc + 8a + 4h + e]
   f32x16 acc[4][2];
+  float res_bias[2] = {0.f, 0.f};        // EPI_RESIDUAL: this tile's bias of the lane's column, J = 0 / 1 (RES_BIAS_LOAD)
   const int nk = g.K / TK;
   frag_t fa[2][4], fb0[4], fb1[4];
 
@@ -337,77 +339,114 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
       }                                                                                                                     \
     }                                                                                                                       \
   } while (0)
-  // ---- EPI_RESIDUAL hooks (file header): unit U = 2 q + rt of the tile at (MM0, NN0); everything is private to the wave.
-  // A unit's 4-KiB image holds its 32 rows x 128 B with the ring's swizzle: logical 16-B chunk c of row r sits in slot c ^ ((r >> 1) & 7).
-  // LDS-DMA piece `it` = rows 8 it .. 8 it + 7: lane L deposits at slot L & 7 of row 8 it + (L >> 3), so it fetches (and, on the way out,
-  // stores) logical chunk (L & 7) ^ ((4 it + (L >> 4)) & 7): one per-lane offset for even pieces, the same ^ 64 B for odd ones.
-  // Rows come in aligned groups of 8 and M % 8 == 0 (launcher): a piece lies wholly inside or outside M (scalar test).
-#define RES_GEOM(U, MM0, NN0)                                                                                               \
-    constexpr int _q = (U) >> 1, _rt = (U) & 1, _I = _q >> 1, _J = (_q == 1 || _q == 2) ? 1 : 0;                             \
-    int _ln = lane;                                                                                                         \
-    asm volatile("" : "+v"(_ln));                                                                                           \
-    const int _rowb = (MM0) + 128 * _I + 64 * wr + 32 * _rt;                                                                \
-    const uint32_t _sbase = (uint32_t)_rowb * (uint32_t)(g.N * 4) + (uint32_t)(((NN0) + 128 * _J + 32 * wc) * 4);           \
-    const uint32_t _vl = (uint32_t)(_ln >> 3) * (uint32_t)(g.N * 4) + (uint32_t)((((_ln & 7) ^ (_ln >> 4)) & 7) << 4);      \
-    const auto _rsx = __builtin_amdgcn_make_buffer_rsrc((void*)g.x, 0, out_bytes, 0x00020000);                              \
-    char* const _img = stage + wid * 4096
+  // ---- EPI_RESIDUAL hooks (file header); everything is private to the wave (its 4 KiB of the staging image).
+  // The accumulator keeps the TOKEN ON THE REGISTER here (operands of the MFMA swapped: same products, same order):
+  //     acc[q][rt][r] = C[m0 + 128 I + 64 wr + 32 rt + 8 (r >> 2) + 4 h + (r & 3)][n0 + 128 J + 32 wc + r31]
+  // so that a row class u = row mod 8 = 4 h + (r & 3) (kernels.h) is the registers r = u (mod 4) of one lane half in all eight blocks.
+  //   x-in, class U of the tile at (m0, n0): the wave's 32 rows of the class -- 8 g + U in each of its four 32-row blocks (I, rt) -- times
+  //   its 32 columns of both J: 32 row segments of 128 B = four LDS-DMA pieces p = 2 J + I of [8 segments rt, g][128 B]; lane L deposits
+  //   the 16-B chunk L & 7 of segment L >> 3.  Read back by ds_read_b32 (lanes 0-31 = the 32 columns of a segment: conflict-free; both lane
+  //   halves read, the half that owns the class adds).
+  //   out, unit (q, rt): bias from a VGPR (the column is the lane), 16 ds_write_b32 into a row-major [32 rows][128 B] image, four lane-linear
+  //   ds_read_b128, four 16-B stores of 8 rows x 128 B.  Rows come in aligned groups of 8 and M % 8 == 0: a piece is inside M or outside.
 #define RES_XDMA(U)                                                                                                         \
   do {                                                                                                                      \
-    RES_GEOM(U, m0, n0);                                                                                                    \
-    (void)_q; (void)_rt;                                                                                                    \
-    _Pragma("unroll") for (int it = 0; it < 4; ++it)                                                                        \
-      if (_rowb + 8 * it < g.M)                                                                                             \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(_rsx, (lds_ptr_t)(_img + it * 1024), 16, _vl ^ ((it & 1) ? 64u : 0u),      \
-                                                 _sbase + (uint32_t)(8 * it) * (uint32_t)(g.N * 4), 0, 0);                  \
+    int _ln = lane;                                                                                                         \
+    asm volatile("" : "+v"(_ln));                                                                                           \
+    const auto _rsx = __builtin_amdgcn_make_buffer_rsrc((void*)g.x, 0, out_bytes, 0x00020000);                              \
+    char* const _img = stage + wid * 4096;                                                                                  \
+    const int _rl = 64 * wr + 32 * (_ln >> 5) + 8 * ((_ln >> 3) & 3) + (U);      /* row inside the 128-row half tile */      \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                                         \
+      const int _row = m0 + 128 * (p & 1) + _rl;                                                                            \
+      uint32_t _off = (uint32_t)_row * (uint32_t)(g.N * 4) + (uint32_t)((n0 + 128 * (p >> 1) + 32 * wc) * 4 + 16 * (_ln & 7)); \
+      _off = _row < g.M ? _off : 0x80000000u;            /* past M: beyond the buffer (x < 2 GiB, launcher): nothing is fetched */ \
+      if (PIO_ROLL_ABL & 8) continue;                                                                                       \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(_rsx, (lds_ptr_t)(_img + p * 1024), 16, _off, 0, 0, 0);                      \
+    }                                                                                                                       \
+  } while (0)
+  // this tile's bias, one column per lane and J: an asm load (no compiler-visible VGPR-destination load in the loop: its wait would
+  // drain the LDS-DMA queue); issued with the first x-in DMA, so the next K-tile's counted wait retires it long before its first use
+#define RES_BIAS_LOAD()                                                                                                     \
+  do {                                                                                                                      \
+    int _ln = lane;                                                                                                         \
+    asm volatile("" : "+v"(_ln));                                                                                           \
+    const uint32_t _bo = (uint32_t)((n0 + 32 * wc + (_ln & 31)) * 4);                                                       \
+    if (PIO_ROLL_ABL & 4) break;                                                                                            \
+    /* s_nop 4: the base may have just been rebuilt by v_readlane (an SGPR spill reload), and a VMEM instruction that reads an SGPR */ \
+    /* written by a VALU needs five wait states -- which hipcc inserts for its own instructions, not inside inline asm (round 5: a  */ \
+    /* stale high half of the pointer = a memory fault) */                                                                  \
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:512"                       \
+                 : "=&v"(res_bias[0]), "=&v"(res_bias[1]) : "v"(_bo), "s"(g.bias) : "memory");                              \
   } while (0)
 #define RES_XADD(U)                                                                                                         \
   do {                                                                                                                      \
-    constexpr int _q = (U) >> 1, _rt = (U) & 1;                                                                             \
     int _ln = lane;                                                                                                         \
     asm volatile("" : "+v"(_ln));                                                                                           \
-    const char* const _b = stage + wid * 4096 + (_ln & 31) * 128;                                                           \
-    f32x4 _t[4];                                                                                                            \
-    _Pragma("unroll") for (int a = 0; a < 4; ++a) _t[a] = *(const f32x4*)(_b + co[a]);                                      \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the reads have returned before the next unit's DMA is issued */ \
-    _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int e = 0; e < 4; ++e)                             \
-      acc[_q][_rt][4 * a + e] += _t[a][e];                                                                                  \
+    const char* const _b = stage + wid * 4096 + (_ln & 31) * 4;                                                             \
+    const bool _mine = (_ln >> 5) == ((U) >> 2);                                                                            \
+    _Pragma("unroll") for (int pj = 0; pj < 2; ++pj) {           /* J = pj: two batches of 16 reads */                      \
+      float _t[2][2][4];                                                                                                    \
+      _Pragma("unroll") for (int pi = 0; pi < 2; ++pi) _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                     \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq)                                                                    \
+          _t[pi][rt][gq] = *(const float*)(_b + (2 * pj + pi) * 1024 + (rt * 4 + gq) * 128);                                \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         /* (the last batch: returned before the next class's DMA is issued) */ \
+      if (_mine) {                                                                                                          \
+        _Pragma("unroll") for (int pi = 0; pi < 2; ++pi) _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                   \
+          _Pragma("unroll") for (int gq = 0; gq < 4; ++gq)                                                                  \
+            acc[pi == 0 ? pj : 3 - pj][rt][4 * gq + ((U) & 3)] += _t[pi][rt][gq];                                           \
+      }                                                                                                                     \
+    }                                                                                                                       \
   } while (0)
 #define RES_OUT(U)                                                                                                          \
   do {                                                                                                                      \
-    RES_GEOM(U, e_m0, e_n0);                                                                                                \
-    if constexpr (_rt == 0) { const int _h = _ln >> 5; ROLL_BIAS(_q, _J, _h); }                                             \
-    char* const _b = _img + (_ln & 31) * 128;                                                                               \
-    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                                           \
-      *(f32x4*)(_b + co[a]) = (f32x4){acc[_q][_rt][4 * a], acc[_q][_rt][4 * a + 1], acc[_q][_rt][4 * a + 2], acc[_q][_rt][4 * a + 3]}; \
+    constexpr int _q = (U) >> 1, _rt = (U) & 1, _I = _q >> 1, _J = (_q == 1 || _q == 2) ? 1 : 0;                             \
+    int _ln = lane;                                                                                                         \
+    asm volatile("" : "+v"(_ln));                                                                                           \
+    const auto _rsx = __builtin_amdgcn_make_buffer_rsrc((void*)g.x, 0, out_bytes, 0x00020000);                              \
+    char* const _img = stage + wid * 4096;                                                                                  \
+    const int _rowb = e_m0 + 128 * _I + 64 * wr + 32 * _rt;                                                                 \
+    const uint32_t _sbase = (uint32_t)_rowb * (uint32_t)(g.N * 4) + (uint32_t)((e_n0 + 128 * _J + 32 * wc) * 4);            \
+    const uint32_t _vl = (uint32_t)(_ln >> 3) * (uint32_t)(g.N * 4) + (uint32_t)((_ln & 7) << 4);                           \
+    char* const _w = _img + (_ln >> 5) * 512 + (_ln & 31) * 4;                                                              \
+    const float _bj = res_bias[_J];                                                                                         \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) *(float*)(_w + (8 * (r >> 2) + (r & 3)) * 128) = acc[_q][_rt][r] + _bj;   \
     _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                                      \
       const u32x4 v = *(const u32x4*)(_img + it * 1024 + 16 * _ln);                                                         \
       if (PIO_ROLL_ABL & 2) { asm volatile("" :: "v"(v)); continue; }                                                       \
       if (_rowb + 8 * it < g.M)                                                                                             \
-        __builtin_amdgcn_raw_buffer_store_b128(v, _rsx, _vl ^ ((it & 1) ? 64u : 0u),                                        \
-                                               _sbase + (uint32_t)(8 * it) * (uint32_t)(g.N * 4), 0);                       \
+        __builtin_amdgcn_raw_buffer_store_b128(v, _rsx, _vl, _sbase + (uint32_t)(8 * it) * (uint32_t)(g.N * 4), 0);         \
     }                                                                                                                       \
   } while (0)
-#define RES_U(U) ((U) < 0 ? 0 : (U))
-  // one slot of the schedule: interval k of a K-tile at position POS, before (PRE) or at the group's usual place; U = the unit whose x
-  // joins in this K-tile (middle K-tiles 2 .. 9 of a tile), or -1
+#define RES_U(U) ((U) < 0 ? 0 : ((U) > 7 ? 7 : (U)))
+  // One slot of the schedule: interval k of a K-tile at position POS, before (PRE) the interval's MFMAs or at the group's usual place.
+  // U: K-tile 1 carries 0, the K-tiles 2 .. 9 of a tile 1 .. 8, every other one -1.  Class u joins after K-tile u + 1 (kernels.h):
+  //   waves 0-3 (hooks after MFMAs): add class u in the LAST interval of K-tile u + 1, then issue the DMA of class u + 1;
+  //                                  the DMA of class 0 (and the bias) in the last interval of K-tile 0, behind the previous tile's last unit
+  //   waves 4-7 (hooks before MFMAs): add class u in the FIRST interval of K-tile u + 2, then issue the DMA of class u + 1;
+  //                                  the DMA of class 0 (and the bias) in the first interval of K-tile 1
+  // either way between the MFMAs of K-tile u + 1 and those of K-tile u + 2 on every quadrant, and a DMA is retired by the counted wait
+  // of the K-tile that follows its issue (it is older than that K-tile's A0 / B0 requests).
 #define RES_SLOT(POS, k, PRE, GRP, U)                                                                                       \
   do {                                                                                                                      \
     if constexpr (EPI == EPI_RESIDUAL) {                                                                                    \
-      if constexpr ((POS) == 1 && (k) == 3 && !(PRE)) RES_XDMA(0);                                                          \
-      if constexpr ((POS) == 2 && (U) >= 0) {                                                                               \
-        if constexpr ((GRP) == 0 ? (!(PRE) && (k) == ((U) >= 6 ? 2 : 3)) : ((PRE) && (k) == 3)) {                           \
-          RES_XADD(RES_U(U));                                                                                               \
-          if constexpr ((U) < 7) RES_XDMA(RES_U(U) + 1);                                                                    \
-        }                                                                                                                   \
-      }                                                                                                                     \
       if constexpr ((GRP) == 0) {                                                                                           \
         if constexpr ((POS) == 4 && !(PRE)) RES_OUT(k);                                                                     \
         if constexpr ((POS) == 0 && !(PRE) && (k) <= 2) { if (has_prev) RES_OUT(4 + (k)); }                                 \
         if constexpr ((POS) == 0 && (PRE)) { if (has_prev) RES_OUT(7); }                                                    \
+        if constexpr ((POS) == 0 && !(PRE) && (k) == 3) { RES_XDMA(0); RES_BIAS_LOAD(); }                                   \
+        if constexpr (((POS) == 1 || (POS) == 2) && (U) >= 0 && (U) <= 7 && !(PRE) && (k) == 3) {                           \
+          RES_XADD(RES_U(U));                                                                                               \
+          if constexpr ((U) < 7) RES_XDMA(RES_U(U) + 1);                                                                    \
+        }                                                                                                                   \
       } else {                                                                                                              \
         if constexpr ((POS) == 4 && !(PRE) && (k) >= 1) RES_OUT(((k) - 1) & 7);                                             \
         if constexpr ((POS) == 0 && !(PRE) && (k) <= 2) { if (has_prev) RES_OUT(3 + (k)); }                                 \
         if constexpr ((POS) == 0 && (PRE)) { if (has_prev) { RES_OUT(6); RES_OUT(7); } }                                    \
+        if constexpr ((POS) == 1 && !(PRE) && (k) == 0) { RES_XDMA(0); RES_BIAS_LOAD(); }                                   \
+        if constexpr ((POS) == 2 && (U) >= 1 && !(PRE) && (k) == 0) {                                                       \
+          RES_XADD(RES_U((U) - 1));                                                                                         \
+          if constexpr ((U) <= 7) RES_XDMA(RES_U(U));                                                                       \
+        }                                                                                                                   \
       }                                                                                                                     \
     }                                                                                                                       \
   } while (0)
@@ -435,7 +474,8 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
     _Pragma("unroll") for (int s = 0; s < 4; ++s) _Pragma("unroll") for (int rt = 0; rt < 2; ++rt) {     \
       f32x16 _c = acc[q][rt];                                                                            \
       if constexpr (ZERO) { if (s == 0) { _Pragma("unroll") for (int r = 0; r < 16; ++r) _c[r] = 0.f; } } \
-      acc[q][rt] = mfma32(fb[s], fa[rt][s], _c);      /* token on the lane */                              \
+      if constexpr (EPI == EPI_RESIDUAL) acc[q][rt] = mfma32(fa[rt][s], fb[s], _c);      /* token on the register (RES_* hooks) */ \
+      else acc[q][rt] = mfma32(fb[s], fa[rt][s], _c);                                    /* token on the lane */     \
     }                                                                                                    \
   } while (0)
 
@@ -538,11 +578,11 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
       const bool has_next = nid < ntiles;                                                                \
       ROLL_STAMP(2 + 5 * _ti);                                                                           \
       KTILE(0, 0, 0, -1);                                                                                \
-      KTILE(1, 1, 1, -1);                                                                                \
+      KTILE(1, 1, 1, 0);                                                                                 \
       ROLL_STAMP(3 + 5 * _ti);                                                                           \
-      if constexpr (EPI == EPI_RESIDUAL) {      /* K-tiles 2 .. 9: the old x joins, one unit per K-tile (nk >= 12: launcher) */ \
-        KTILE(2, 2, 0, 0); KTILE(2, 3, 1, 1); KTILE(2, 4, 0, 2); KTILE(2, 5, 1, 3);                      \
-        KTILE(2, 6, 0, 4); KTILE(2, 7, 1, 5); KTILE(2, 8, 0, 6); KTILE(2, 9, 1, 7);                      \
+      if constexpr (EPI == EPI_RESIDUAL) {      /* K-tiles 1 .. 9: the old x joins, one row class per K-tile (nk >= 12: launcher) */ \
+        KTILE(2, 2, 0, 1); KTILE(2, 3, 1, 2); KTILE(2, 4, 0, 3); KTILE(2, 5, 1, 4);                      \
+        KTILE(2, 6, 0, 5); KTILE(2, 7, 1, 6); KTILE(2, 8, 0, 7); KTILE(2, 9, 1, 8);                      \
         for (int t = 10; t < nk - 2; t += 2) { KTILE(2, t, 0, -1); KTILE(2, t + 1, 1, -1); }             \
       } else {                                                                                           \
         for (int t = 2; t < nk - 2; t += 2) { KTILE(2, t, 0, -1); KTILE(2, t + 1, 1, -1); }              \
@@ -615,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
 #undef RES_OUT
 #undef RES_XADD
 #undef RES_XDMA
-#undef RES_GEOM
+#undef RES_BIAS_LOAD
 #undef ROLL_SPLIT
 #undef ROLL_OFFSETS
 

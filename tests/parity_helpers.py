@@ -38,11 +38,14 @@ MARGIN_BOUND = 1e-3
 PREFIX_REL_BOUND = {"fp16": 2e-2, "bf16": 8e-2}
 DEPART_FRACTION = 0.03
 # bf16 operands carry 8 significant bits where fp16 carries 11: the backbone's rounding error, the prefix error behind the T = 0.01
-# projection and the logit shifts all scale by 8, so the bf16 ceilings are the fp16 ones x 8 for the margin, x 4 for the prefix
-# (fp16 measured 4.1e-3 under its 2e-2) and a larger share of captions may sit at a (wider) near-tie.  Used by the one bf16
+# projection and the logit shifts all scale by 8.  Measured on the one bf16 end-to-end set (24 captions, two builds of round 5): prefix
+# error 2.0e-2 / 3.3e-2 relative L2 (fp16: 2e-3), 1 and 3 captions departing, at reference margins 2.9e-4 and 1.0e-2 with logit shifts of
+# 7.5e-3 / 3.1e-2.  The ceilings leave a factor ~3 over that: margin 3e-2 (fp16: 1e-3), prefix 8e-2 (fp16: 2e-2), at most 4 of 24
+# captions.  README states what this means: bf16 is a backbone mode for throughput experiments, fp16 is the default because its captions
+# follow the fp32 reference (2 departures in ~790).  Used by the one bf16
 # end-to-end test (test_gpu_parity.py::test_e2e_full_depth_bf16_backbone_ledger); every other test runs the fp16 default.
-MARGIN_BOUND_BY = {"fp16": MARGIN_BOUND, "bf16": 5e-2}
-DEPART_FRACTION_BY = {"fp16": DEPART_FRACTION, "bf16": 0.25}
+MARGIN_BOUND_BY = {"fp16": MARGIN_BOUND, "bf16": 3e-2}
+DEPART_FRACTION_BY = {"fp16": DEPART_FRACTION, "bf16": 0.17}
 REPORT = []          # one record per assert_ids_explained call; conftest.pytest_terminal_summary prints and saves them
 REPORT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_parity_report.json")
 
