@@ -149,3 +149,65 @@ def test_no_mfma_destination_is_touched_inside_its_hazard_window(tmp_path):
     bad, seen = scan_mfma(LIB, tmp_path)
     assert seen > 5000, seen
     assert not bad, "an MFMA's destination is read or overwritten before its wait states have passed:\n" + "\n".join(bad[:20])
+
+
+def _sregs(tok):
+    """sN or s[a:b] -> set of SGPR numbers"""
+    out = set()
+    for m in re.finditer(r"s\[(\d+):(\d+)\]|(?<![a-z_\d])s(\d+)(?![\d:])", tok):
+        if m.group(1) is not None:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def scan_valu_sgpr_vmem(path, tmp_path):
+    """Third hazard hipcc cannot see inside inline asm (round 5: a memory fault): a VMEM instruction that reads an SGPR (address base,
+    resource, scalar offset) which a VALU instruction wrote (v_readlane / v_readfirstlane: SGPR spill reloads; VOP3 compares) needs
+    FIVE wait states in between (GCNHazardRecogniser: checkVMEMHazards, VmemSgprWaitStates).  An asm `global_load ..., s[a:b]` whose
+    pointer had just been reloaded by v_readlane read the stale high half.  -> (violations, VALU SGPR writes seen)"""
+    lib = os.path.join(tmp_path, "lib3.so")
+    shutil.copy(path, lib)
+    subprocess.run([OBJDUMP, "--offloading", lib], check=True, capture_output=True, cwd=tmp_path)
+    objs = [os.path.join(tmp_path, f) for f in os.listdir(tmp_path) if "gfx950" in f]
+    bad, seen = [], 0
+    for o in objs:
+        dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", o], check=True, capture_output=True, text=True).stdout
+        func, pend = None, []                                      # pend: (SGPRs written, wait states still needed, text)
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                func, pend = m.group(1), []
+                continue
+            ins = line.strip().split("//")[0].strip()
+            if not ins or ins.endswith(":"):
+                continue
+            parts = ins.split(None, 1)
+            op, args = parts[0], (parts[1] if len(parts) > 1 else "")
+            toks = [t.strip() for t in args.split(",")]
+            if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                pend = []
+                continue
+            if op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+                read = set()
+                for t in toks[1:] if not op.startswith(("buffer_store", "global_store", "scratch_store", "flat_store")) else toks:
+                    read |= _sregs(t)
+                for dst, left, text in pend:
+                    if read & dst:
+                        bad.append("%s: %s -> (%d wait states short) %s" % (func, text, left, ins))
+            step = int(toks[0], 0) + 1 if op == "s_nop" else 1
+            pend = [(d, left - step, t) for d, left, t in pend if left - step > 0]
+            if op.startswith(("v_readlane_b32", "v_readfirstlane_b32")) or (op.startswith("v_cmp") and op.endswith("_e64")):
+                d = _sregs(toks[0])
+                if d:
+                    seen += 1
+                    pend.append((d, 5, ins))
+    return bad, seen
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="needs the built library and llvm-objdump")
+def test_no_vmem_instruction_reads_an_sgpr_a_valu_has_just_written(tmp_path):
+    bad, seen = scan_valu_sgpr_vmem(LIB, tmp_path)
+    assert seen > 500, seen
+    assert not bad, "a VMEM instruction reads an SGPR written by a VALU fewer than five wait states earlier:\n" + "\n".join(bad[:20])
