@@ -57,15 +57,17 @@ __device__ __forceinline__ void gemm_warm_next(const GemmArgs& g, int e, int ne,
 // EPI_RESIDUAL, the arithmetic EVERY GEMM kernel follows (one definition, so that an element of x never depends on the kernel, the
 // launch size or the image's place in the launch that produced it).  LayerScale is folded into the operands at load (api.cpp:
 // W' = op(ls[n] W[n][k]), b' = ls[n] b[n]), and
-//     x_new[m][n] = ( sum over k ascending in MFMA steps of 16, from 0, with the OLD x[m][n] joining the sum after K-tile J(m) ) + b'[n]
-// where a K-tile is 64 consecutive k and J(m) = min((m mod 8) + 1, K / 64 - 1): the class of a row is its index mod 8, which is the
-// same wherever its image sits in a launch (images start at multiples of 8 rows: Tp % 8 == 0) -- a first version keyed the class to
-// the row's place in the 256-row tile and an image's tokens changed bits with its position in the batch.  Why x joins in the MIDDLE of
-// the sum: the persistent kernel (vit_gemm_roll.hip) fetches x one class per K-tile through 32 KiB of LDS while the multiplies run,
-// so that the fp32 read of the residual stream costs no time of its own; at the end (or the start) of the sum all of a tile's x would be
-// needed at once.  With the token on the accumulator REGISTER (32 x 32 MFMA: register r of lane-half h holds row 8 (r >> 2) + 4 h +
-// (r & 3)) a class is the registers r = c (mod 4) of the lanes of one half: u = 4 h + c.
-__host__ __device__ constexpr int resid_join_ktile(int u, int nk) { return u + 1 < nk - 1 ? u + 1 : nk - 1; }
+//     x_new[m][n] = ( sum over k ascending in MFMA steps of 16, from 0, with the OLD x[m][n] joining the sum after K-tile J(m, n) ) + b'[n]
+// where a K-tile is 64 consecutive k and J(m, n) = min(e + 1, K / 64 - 1) with the class e = (m mod 4) + 4 ((n mod 256) / 128): the row's
+// index mod 4 is the same wherever its image sits in a launch (images start at multiples of 8 rows: Tp % 8 == 0), the column half of the
+// 256-grid always is -- a first version keyed the class to the row's place in the 256-row tile and an image's tokens changed bits
+// with its position in the batch.  Why x joins in the MIDDLE of the sum: the persistent kernel (vit_gemm_roll.hip) fetches x one class
+// per K-tile through 32 KiB of LDS while the multiplies run, so that the fp32 read of the residual stream costs no time of its own; at
+// the end (or the start) of the sum all of a tile's x would be needed at once.  With the token on the accumulator REGISTER (32 x 32
+// MFMA: register r of lane-half h holds row 8 (r >> 2) + 4 h + (r & 3)) a class is the registers r = c (mod 4) of EVERY lane, in the
+// blocks of one column half.
+__host__ __device__ constexpr int resid_class(int m, int n) { return (m & 3) + 4 * ((n >> 7) & 1); }
+__host__ __device__ constexpr int resid_join_ktile(int e, int nk) { return e + 1 < nk - 1 ? e + 1 : nk - 1; }
 
 hipError_t launch_vit_gemm(OperandType t, GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
 // 256 x 256 tiles, 8 waves (vit_gemm256.hip): same arithmetic per output element; launch_vit_gemm dispatches to it

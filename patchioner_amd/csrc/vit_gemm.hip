@@ -112,23 +112,21 @@ __global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? PIO_GEMM_WIDE_OCC
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // EPI_RESIDUAL (kernels.h: resid_join_ktile): the old x of this wave's elements, loaded up front (32 registers per 32-row block: this
-  // kernel has them to spare) and added to the running sums after the K-tile the canonical order names: class u = row mod 8 = 4 h + (r & 3)
-  // (a block of 32 rows starts at a multiple of 32), i.e. after K-tile J(u) the lanes of half u >> 2 add their registers r = u (mod 4).
-  const int nk = g.K / BK;                  // even and >= 2 (checked by the launcher)
+  // EPI_RESIDUAL (kernels.h: resid_join_ktile): the old x of this wave's elements joins the running sums after the K-tile the canonical
+  // order names: class e = (row mod 4) + 4 (column half of the 256-grid) -- the registers r = c (mod 4) of every lane (a block of 32 rows
+  // starts at a multiple of 32), the column half being the same for the whole workgroup (BN = 128).
   // Two forms.  NBUF == 3 (64-row tiles): all of the wave's x up front, 32 registers.  NBUF < 3 (128-row tiles; every barrier there
   // follows an s_waitcnt vmcnt(0), PIO_LANDED): one class at a time, fetched a K-tile before it joins -- holding 64 registers of x
   // beside 64 of sums spilled into the main loop (round 5).  The one-class buffer needs every class on a K-tile of its own: nk >= 10
   // (launcher).
+  const int nk = g.K / BK;                  // even and >= 2 (checked by the launcher)
   constexpr bool XLAZY = EPI == EPI_RESIDUAL && NBUF != 3;
   float xin[EPI == EPI_RESIDUAL && !XLAZY ? MI : 1][2][16];
   float xlz[XLAZY ? MI : 1][2][4];
-  int xjk[4] = {0, 0, 0, 0};               // per lane: the K-tile after which its registers r = c (mod 4) take their x in
+  const int xj0 = 4 * ((n0 >> 7) & 1);      // classes xj0 .. xj0 + 3 live in this workgroup
 #define PIO_X_INDEX(i, j, r) ((uint32_t)min(m0 + wm * (BM / 2) + (i) * 32 + acc_row32((r), lane), g.M - 1) * (uint32_t)g.N + \
                              (uint32_t)(n0 + wn * 64 + (j) * 32 + r31))      /* rows past M: a copy of the last row, never stored; M N < 2^30 (launcher) */
   if constexpr (EPI == EPI_RESIDUAL && !XLAZY) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) xjk[c] = resid_join_ktile(4 * h + c, nk);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -136,16 +134,16 @@ __global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? PIO_GEMM_WIDE_OCC
 #pragma unroll
         for (int r = 0; r < 16; ++r) xin[i][j][r] = g.x[PIO_X_INDEX(i, j, r)];
   }
-  // the class that joins after K-tile ktn, into the one-class buffer (lazy form): u = ktn - 1 is scalar, so ONE block of loads
-  // serves every class (the rows 8 gq + 4 h + (u & 3) of a 32-row block); the adds need the register index at compile time
+  // the class that joins after K-tile ktn, into the one-class buffer (lazy form): its register residue c is scalar, so ONE block of
+  // loads serves every class (the rows 8 gq + 4 h + c of a 32-row block); the adds need the register index at compile time
 #define PIO_FETCH_X(ktn)                                                                               \
   do {                                                                                                 \
     if constexpr (XLAZY) {                                                                             \
-      const int _u = (ktn) - 1;                                                                        \
-      if (_u >= 0 && _u < 8 && h == (_u >> 2)) {                                                       \
+      const int _c = (ktn) - 1 - xj0;                                                                  \
+      if (_c >= 0 && _c < 4) {                                                                         \
         _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)   \
           _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                           \
-            const int _m = min(m0 + wm * (BM / 2) + i * 32 + 8 * gq + 4 * h + (_u & 3), g.M - 1);      \
+            const int _m = min(m0 + wm * (BM / 2) + i * 32 + 8 * gq + 4 * h + _c, g.M - 1);            \
             xlz[i][j][gq] = g.x[(uint32_t)_m * (uint32_t)g.N + (uint32_t)(n0 + wn * 64 + j * 32 + r31)]; \
           }                                                                                            \
       }                                                                                                \
@@ -154,18 +152,16 @@ __global__ __launch_bounds__(256, BM >= 256 ? 2 : (NBUF == 1 ? PIO_GEMM_WIDE_OCC
 #define PIO_JOIN_X(kt)                                                                                 \
   do {                                                                                                 \
     if constexpr (XLAZY) {                                                                             \
-      const int _u = (kt) - 1;                                                                         \
-      if (_u >= 0 && _u < 8 && h == (_u >> 2)) {                                                       \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                  \
-          if ((_u & 3) == c) {                                                                         \
-            _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
-              _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) acc[i][j][4 * gq + c] += xlz[i][j][gq]; \
-          }                                                                                            \
-      }                                                                                                \
+      const int _c = (kt) - 1 - xj0;                                                                   \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                    \
+        if (_c == c) {                                                                                 \
+          _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+            _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) acc[i][j][4 * gq + c] += xlz[i][j][gq];   \
+        }                                                                                              \
       PIO_FETCH_X((kt) + 1);                                                                           \
     } else if constexpr (EPI == EPI_RESIDUAL) {                                                        \
       _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                    \
-        if (xjk[c] == (kt)) {                    /* per lane half: skipped when no lane of the wave joins here */ \
+        if (resid_join_ktile(xj0 + c, nk) == (kt)) {                                                   \
           _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
             _Pragma("unroll") for (int gq = 0; gq < 4; ++gq)                                           \
               acc[i][j][4 * gq + c] += xin[i][j][4 * gq + c];                                          \

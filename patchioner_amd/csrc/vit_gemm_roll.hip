@@ -201,6 +201,7 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
   // acc[q][rt][4a+e] = C[m0 + 128 I + 64 wr + 32 rt + r31][n0 + 128 J + 32 wc + 8a + 4h + e]
   f32x16 acc[4][2];
   float res_bias[2] = {0.f, 0.f};        // EPI_RESIDUAL: this tile's bias of the lane's column, J = 0 / 1 (RES_BIAS_LOAD)
+  float res_xt[EPI == EPI_RESIDUAL ? 16 : 1];   // ... and the class of x that joins next, between RES_XREAD and RES_XADD
   const int nk = g.K / TK;
   frag_t fa[2][4], fb0[4], fb1[4];
 
@@ -342,23 +343,26 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
   // ---- EPI_RESIDUAL hooks (file header); everything is private to the wave (its 4 KiB of the staging image).
   // The accumulator keeps the TOKEN ON THE REGISTER here (operands of the MFMA swapped: same products, same order):
   //     acc[q][rt][r] = C[m0 + 128 I + 64 wr + 32 rt + 8 (r >> 2) + 4 h + (r & 3)][n0 + 128 J + 32 wc + r31]
-  // so that a row class u = row mod 8 = 4 h + (r & 3) (kernels.h) is the registers r = u (mod 4) of one lane half in all eight blocks.
-  //   x-in, class U of the tile at (m0, n0): the wave's 32 rows of the class -- 8 g + U in each of its four 32-row blocks (I, rt) -- times
-  //   its 32 columns of both J: 32 row segments of 128 B = four LDS-DMA pieces p = 2 J + I of [8 segments rt, g][128 B]; lane L deposits
-  //   the 16-B chunk L & 7 of segment L >> 3.  Read back by ds_read_b32 (lanes 0-31 = the 32 columns of a segment: conflict-free; both lane
-  //   halves read, the half that owns the class adds).
+  // so that a class E = (row mod 4) + 4 J (kernels.h) is the registers r = E & 3 (mod 4) of EVERY lane in the four blocks (I, rt) of column
+  // half J = E >> 2: 16 registers per lane.
+  //   x-in, class E of the tile at (m0, n0): the wave's 32 rows of the class in each of its ... four blocks hold 8 (rows 8 g + 4 h' + c,
+  //   g = 0 .. 3, h' = 0 / 1) -- times its 32 columns of half J: 32 row segments of 128 B = four LDS-DMA pieces p = 2 I + rt of
+  //   [8 segments h', g][128 B]; lane L deposits the 16-B chunk L & 7 of segment L >> 3.  Read back by ds_read_b32 (lanes 0-31 = the 32
+  //   columns of segment (h' = 0, g), lanes 32-63 of (h' = 1, g): conflict-free) one slot BEFORE the adds, so that the LDS latency passes
+  //   under the interval's MFMAs or the barrier.
   //   out, unit (q, rt): bias from a VGPR (the column is the lane), 16 ds_write_b32 into a row-major [32 rows][128 B] image, four lane-linear
   //   ds_read_b128, four 16-B stores of 8 rows x 128 B.  Rows come in aligned groups of 8 and M % 8 == 0: a piece is inside M or outside.
-#define RES_XDMA(U)                                                                                                         \
+#define RES_XDMA(E)                                                                                                         \
   do {                                                                                                                      \
     int _ln = lane;                                                                                                         \
     asm volatile("" : "+v"(_ln));                                                                                           \
     const auto _rsx = __builtin_amdgcn_make_buffer_rsrc((void*)g.x, 0, out_bytes, 0x00020000);                              \
     char* const _img = stage + wid * 4096;                                                                                  \
-    const int _rl = 64 * wr + 32 * (_ln >> 5) + 8 * ((_ln >> 3) & 3) + (U);      /* row inside the 128-row half tile */      \
+    const int _rl = 64 * wr + 8 * ((_ln >> 3) & 3) + 4 * (_ln >> 5) + ((E) & 3);      /* row inside a 128-row half tile, block rt = 0 */ \
+    const uint32_t _cb = (uint32_t)((n0 + 128 * ((E) >> 2) + 32 * wc) * 4 + 16 * (_ln & 7));                                \
     _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                                         \
-      const int _row = m0 + 128 * (p & 1) + _rl;                                                                            \
-      uint32_t _off = (uint32_t)_row * (uint32_t)(g.N * 4) + (uint32_t)((n0 + 128 * (p >> 1) + 32 * wc) * 4 + 16 * (_ln & 7)); \
+      const int _row = m0 + 128 * (p >> 1) + 32 * (p & 1) + _rl;                                                            \
+      uint32_t _off = (uint32_t)_row * (uint32_t)(g.N * 4) + _cb;                                                           \
       _off = _row < g.M ? _off : 0x80000000u;            /* past M: beyond the buffer (x < 2 GiB, launcher): nothing is fetched */ \
       if (PIO_ROLL_ABL & 8) continue;                                                                                       \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(_rsx, (lds_ptr_t)(_img + p * 1024), 16, _off, 0, 0, 0);                      \
@@ -374,28 +378,23 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
     if (PIO_ROLL_ABL & 4) break;                                                                                            \
     /* s_nop 4: the base may have just been rebuilt by v_readlane (an SGPR spill reload), and a VMEM instruction that reads an SGPR */ \
     /* written by a VALU needs five wait states -- which hipcc inserts for its own instructions, not inside inline asm (round 5: a  */ \
-    /* stale high half of the pointer = a memory fault) */                                                                  \
+    /* stale high half of the pointer = a memory fault; tests/test_isa_hazards_cpu.py scans the built library for it) */    \
     asm volatile("s_nop 4\n\tglobal_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:512"                       \
                  : "=&v"(res_bias[0]), "=&v"(res_bias[1]) : "v"(_bo), "s"(g.bias) : "memory");                              \
   } while (0)
-#define RES_XADD(U)                                                                                                         \
+#define RES_XREAD(E)                                                                                                        \
   do {                                                                                                                      \
     int _ln = lane;                                                                                                         \
     asm volatile("" : "+v"(_ln));                                                                                           \
-    const char* const _b = stage + wid * 4096 + (_ln & 31) * 4;                                                             \
-    const bool _mine = (_ln >> 5) == ((U) >> 2);                                                                            \
-    _Pragma("unroll") for (int pj = 0; pj < 2; ++pj) {           /* J = pj: two batches of 16 reads */                      \
-      float _t[2][2][4];                                                                                                    \
-      _Pragma("unroll") for (int pi = 0; pi < 2; ++pi) _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                     \
-        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq)                                                                    \
-          _t[pi][rt][gq] = *(const float*)(_b + (2 * pj + pi) * 1024 + (rt * 4 + gq) * 128);                                \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         /* (the last batch: returned before the next class's DMA is issued) */ \
-      if (_mine) {                                                                                                          \
-        _Pragma("unroll") for (int pi = 0; pi < 2; ++pi) _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                   \
-          _Pragma("unroll") for (int gq = 0; gq < 4; ++gq)                                                                  \
-            acc[pi == 0 ? pj : 3 - pj][rt][4 * gq + ((U) & 3)] += _t[pi][rt][gq];                                           \
-      }                                                                                                                     \
-    }                                                                                                                       \
+    const char* const _b = stage + wid * 4096 + (_ln >> 5) * 512 + (_ln & 31) * 4;                                          \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) _Pragma("unroll") for (int gq = 0; gq < 4; ++gq)                          \
+      res_xt[4 * p + gq] = *(const float*)(_b + p * 1024 + gq * 128);                                                       \
+  } while (0)
+#define RES_XADD(E)                                                                                                         \
+  do {                                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     /* RES_XREAD's values are here (and the image is free for the next class's DMA) */ \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) _Pragma("unroll") for (int gq = 0; gq < 4; ++gq)                          \
+      acc[(p >> 1) == 0 ? ((E) >> 2) : 3 - ((E) >> 2)][p & 1][4 * gq + ((E) & 3)] += res_xt[4 * p + gq];                    \
   } while (0)
 #define RES_OUT(U)                                                                                                          \
   do {                                                                                                                      \
@@ -418,32 +417,37 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
     }                                                                                                                       \
   } while (0)
 #define RES_U(U) ((U) < 0 ? 0 : ((U) > 7 ? 7 : (U)))
-  // One slot of the schedule: interval k of a K-tile at position POS, before (PRE) the interval's MFMAs or at the group's usual place.
-  // U: K-tile 1 carries 0, the K-tiles 2 .. 9 of a tile 1 .. 8, every other one -1.  Class u joins after K-tile u + 1 (kernels.h):
-  //   waves 0-3 (hooks after MFMAs): add class u in the LAST interval of K-tile u + 1, then issue the DMA of class u + 1;
+  // One slot of the schedule: interval k of a K-tile at position POS; PRE = 1 before the interval's MFMAs, 0 at the group's usual place,
+  // 2 behind the MFMAs of interval 3 (waves 4-7 only).  U: K-tile 1 carries 0, the K-tiles 2 .. 9 of a tile 1 .. 8, every other one -1.
+  // Class e joins after K-tile e + 1 (kernels.h):
+  //   waves 0-3 (hooks after MFMAs): K-tile e + 1, interval 3: reads before its MFMAs, adds behind them, then the DMA of class e + 1;
   //                                  the DMA of class 0 (and the bias) in the last interval of K-tile 0, behind the previous tile's last unit
-  //   waves 4-7 (hooks before MFMAs): add class u in the FIRST interval of K-tile u + 2, then issue the DMA of class u + 1;
-  //                                  the DMA of class 0 (and the bias) in the first interval of K-tile 1
-  // either way between the MFMAs of K-tile u + 1 and those of K-tile u + 2 on every quadrant, and a DMA is retired by the counted wait
-  // of the K-tile that follows its issue (it is older than that K-tile's A0 / B0 requests).
+  //   waves 4-7 (hooks before MFMAs): reads behind the MFMAs of K-tile e + 1's interval 3, adds in the FIRST interval of K-tile e + 2 (before
+  //                                  its MFMAs), then the DMA of class e + 1; the DMA of class 0 (and the bias) in the first interval of K-tile 1
+  // either way between the MFMAs of K-tile e + 1 and those of K-tile e + 2 on every quadrant, and a DMA is retired by the counted wait
+  // of the K-tile that follows its issue (it is older than that K-tile's A0 / B0 requests), before the reads of its class are issued.
 #define RES_SLOT(POS, k, PRE, GRP, U)                                                                                       \
   do {                                                                                                                      \
     if constexpr (EPI == EPI_RESIDUAL) {                                                                                    \
       if constexpr ((GRP) == 0) {                                                                                           \
-        if constexpr ((POS) == 4 && !(PRE)) RES_OUT(k);                                                                     \
-        if constexpr ((POS) == 0 && !(PRE) && (k) <= 2) { if (has_prev) RES_OUT(4 + (k)); }                                 \
-        if constexpr ((POS) == 0 && (PRE)) { if (has_prev) RES_OUT(7); }                                                    \
-        if constexpr ((POS) == 0 && !(PRE) && (k) == 3) { RES_XDMA(0); RES_BIAS_LOAD(); }                                   \
-        if constexpr (((POS) == 1 || (POS) == 2) && (U) >= 0 && (U) <= 7 && !(PRE) && (k) == 3) {                           \
-          RES_XADD(RES_U(U));                                                                                               \
-          if constexpr ((U) < 7) RES_XDMA(RES_U(U) + 1);                                                                    \
+        if constexpr ((POS) == 4 && (PRE) == 0) RES_OUT(k);                                                                 \
+        if constexpr ((POS) == 0 && (PRE) == 0 && (k) <= 2) { if (has_prev) RES_OUT(4 + (k)); }                             \
+        if constexpr ((POS) == 0 && (PRE) == 1) { if (has_prev) RES_OUT(7); }                                               \
+        if constexpr ((POS) == 0 && (PRE) == 0 && (k) == 3) { RES_XDMA(0); RES_BIAS_LOAD(); }                               \
+        if constexpr (((POS) == 1 || (POS) == 2) && (U) >= 0 && (U) <= 7 && (k) == 3) {                                     \
+          if constexpr ((PRE) == 1) RES_XREAD(RES_U(U));                                                                    \
+          if constexpr ((PRE) == 0) {                                                                                       \
+            RES_XADD(RES_U(U));                                                                                             \
+            if constexpr ((U) < 7) RES_XDMA(RES_U(U) + 1);                                                                  \
+          }                                                                                                                 \
         }                                                                                                                   \
       } else {                                                                                                              \
-        if constexpr ((POS) == 4 && !(PRE) && (k) >= 1) RES_OUT(((k) - 1) & 7);                                             \
-        if constexpr ((POS) == 0 && !(PRE) && (k) <= 2) { if (has_prev) RES_OUT(3 + (k)); }                                 \
-        if constexpr ((POS) == 0 && (PRE)) { if (has_prev) { RES_OUT(6); RES_OUT(7); } }                                    \
-        if constexpr ((POS) == 1 && !(PRE) && (k) == 0) { RES_XDMA(0); RES_BIAS_LOAD(); }                                   \
-        if constexpr ((POS) == 2 && (U) >= 1 && !(PRE) && (k) == 0) {                                                       \
+        if constexpr ((POS) == 4 && (PRE) == 0 && (k) >= 1) RES_OUT(((k) - 1) & 7);                                         \
+        if constexpr ((POS) == 0 && (PRE) == 0 && (k) <= 2) { if (has_prev) RES_OUT(3 + (k)); }                             \
+        if constexpr ((POS) == 0 && (PRE) == 1) { if (has_prev) { RES_OUT(6); RES_OUT(7); } }                               \
+        if constexpr ((POS) == 1 && (PRE) == 0 && (k) == 0) { RES_XDMA(0); RES_BIAS_LOAD(); }                               \
+        if constexpr (((POS) == 1 || (POS) == 2) && (U) >= 0 && (U) <= 7 && (PRE) == 2) RES_XREAD(RES_U(U));                \
+        if constexpr ((POS) == 2 && (U) >= 1 && (PRE) == 0 && (k) == 0) {                                                   \
           RES_XADD(RES_U((U) - 1));                                                                                         \
           if constexpr ((U) <= 7) RES_XDMA(RES_U(U));                                                                       \
         }                                                                                                                   \
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
     ROLL_HOOKS(POS, 2, 1, U); ROLL_SB();                                                                 \
     ROLL_READ_A(BUF, 1); ROLL_DMA2(POS, t, BUF); ROLL_SB(); ROLL_MMA(2, fb1, (POS) == 0); ROLL_WAIT2(POS); ROLL_BARRIER(); \
     ROLL_PREHOOK3(POS, 1, U); ROLL_HOOKS(POS, 3, 1, U); ROLL_SB();                                       \
-    ROLL_DMA3(POS, t, BUF); ROLL_SB(); ROLL_MMA(3, fb0, (POS) == 0); ROLL_BARRIER();                     \
+    ROLL_DMA3(POS, t, BUF); ROLL_SB(); ROLL_MMA(3, fb0, (POS) == 0); ROLL_SB(); RES_SLOT(POS, 3, 2, 1, U); ROLL_BARRIER(); \
   } while (0)
 
   // ---- the tile walk of one wave group
@@ -654,6 +658,7 @@ __global__ __launch_bounds__(512, 2) void k_vit_gemm_roll(const GemmArgs g) {
 #undef RES_U
 #undef RES_OUT
 #undef RES_XADD
+#undef RES_XREAD
 #undef RES_XDMA
 #undef RES_BIAS_LOAD
 #undef ROLL_SPLIT

@@ -132,7 +132,7 @@ static int check(int B, int side, int D, bool bf) {
         const float* xg = (const float*)(got.data() + b.sz_out16 + 3 * b.sz_qk);
         size_t cnt[8] = {0}, tot[8] = {0}; double worst = 0; size_t tcol[16] = {0};
         for (int m = 0; m < g.M; ++m) for (int n = 0; n < g.N; ++n) {
-          const int u = m & 7; ++tot[u];
+          const int u = resid_class(m, n); ++tot[u];
           const float a = xr[(size_t)m * g.N + n], bb = xg[(size_t)m * g.N + n];
           if (a != bb) { ++cnt[u]; ++tcol[(n / 256) & 15]; worst = std::max(worst, (double)fabsf(a - bb) / (fabs(a) + 1e-30)); }
         }
