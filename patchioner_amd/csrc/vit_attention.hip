@@ -54,9 +54,13 @@ namespace pio {
 #ifndef PIO_ATTN_PLAIN_VALU   // 1: the softmax's FMAs / adds as plain VALU instructions (see the kernel)
 #define PIO_ATTN_PLAIN_VALU 1
 #endif
-#ifndef PIO_ATTN_VSWZ_PARITY  // 1: the V^T staging image's swizzle includes the row's parity (round 5; 0 = rounds 2-4, for the A/B build)
-#define PIO_ATTN_VSWZ_PARITY 1
-#endif
+#ifndef PIO_ATTN_VSWZ_PARITY  // 1: the V^T staging image's swizzle includes the row's parity: no LDS bank conflict is left in the kernel
+#define PIO_ATTN_VSWZ_PARITY 0   // (rocprofv3: SQ_LDS_BANK_CONFLICT 0 against 0.178 of the LDS cycles) -- and it is 3-5 % SLOWER (42.4 against 41.1 us
+#endif                           // at 64 images, 50.5 against 48.0 at 80, twice each on one box; profiles/r05_attention_pmc.json): the conflicts
+                                 // were two-way ones on four 8-byte staging stores per thread and tile, which cost a store nothing until its
+                                 // LDS-array cycles exceed its issue cycles (MI355X_MICROARCH.md).  Off.  Also measured in round 5 and not
+                                 // kept: workgroups of FIVE waves for T = 261 (9 query tiles = 2 x 5 instead of 3 x 4 waves, a third fewer
+                                 // workgroups staging K / V^T; same bits): 21.8 against 17.3 us at 16 images, 62.7 against 41.3 at 64.
 #ifndef PIO_ATTN_OCC          // waves per SIMD k_vit_attention is compiled for: 2 (144 VGPRs, three workgroups per CU in practice);
 #define PIO_ATTN_OCC 2         // 4 = 128 VGPRs with 56 B of scratch, measured: see the file header
 #endif
@@ -123,11 +127,12 @@ __global__ __launch_bounds__(256, PIO_ATTN_OCC) void k_vit_attention(const VitAt
   for (int i = 0; i < 2; ++i) {
     const int row = row0 + 32 * i, swz = (row >> 1) & 7;
     lds_off[i] = row * 128 + ((kc ^ swz) << 4);
-    // (round 5) ... XORed with the row's parity as well: a ds_write_b64 is served in groups of 16 lanes = two neighbouring rows, which
-    // share (row >> 1) & 7 and -- 128 B apart -- the same banks: both wrote slots {j, 2 + j, 4 + j, 6 + j} and every such store took two
-    // passes (SQ_LDS_BANK_CONFLICT 0.18 of the LDS cycles for three rounds: four of these stores per thread and tile against 16 fragment
-    // reads per wave).  Now the odd row writes the other four slots.  The fragment reads stay conflict-free: a read group's even and odd
-    // rows sit in different bank halves, and inside each half the extra XOR is the same for every lane.
+    // (round 5, PIO_ATTN_VSWZ_PARITY) ... optionally XORed with the row's parity as well: a ds_write_b64 is served in groups of 16 lanes
+    // = two neighbouring rows, which share (row >> 1) & 7 and -- 128 B apart -- the same banks: both write slots {j, 2 + j, 4 + j, 6 + j}
+    // and every such store takes two passes (SQ_LDS_BANK_CONFLICT 0.18 of the LDS cycles since round 2: four of these stores per thread
+    // and tile against 16 fragment reads per wave).  With the parity the odd row writes the other four slots and the counter reads 0; the
+    // fragment reads stay conflict-free (a read group's even and odd rows sit in different bank halves, and inside each half the extra XOR
+    // is the same for every lane).  It buys no time (see the switch above).
     const int swv = swz ^ (PIO_ATTN_VSWZ_PARITY ? (row & 1) : 0);
     lds_off_v[i][0] = row * 128 + ((((kc & ~1) + 0) ^ swv) << 4) + (kc & 1) * 8;
     lds_off_v[i][1] = row * 128 + ((((kc & ~1) + 1) ^ swv) << 4) + (kc & 1) * 8;
