@@ -119,6 +119,7 @@ struct pio_context {
   std::map<GraphKey, hipGraphExec_t> graphs;
   hipStream_t capture_stream = nullptr;
   bool use_graph = true;
+  bool batched_prefill = true;                    // prompted decodes take their prompt through the layers in one batch (PIO_DEC_PREFILL=0 at pio_create: position by position)
   // inversion
   float *A_pinv = nullptr, *inv_b = nullptr;
   // ViECap head (viecap.hip): mapping network weights / workspaces, entity embeddings, prompt buffer
@@ -129,6 +130,8 @@ struct pio_context {
   float *map_lin = nullptr, *map_x = nullptr, *map_ln = nullptr, *map_q = nullptr, *map_kv = nullptr, *map_att = nullptr, *map_hid = nullptr;
   float* ent = nullptr; int ent_K = 0;            // [K][C] L2-normalised entity text embeddings
   float* prompt_buf = nullptr;                    // [max_prefixes][max_steps][E]
+  float *pre_x = nullptr, *pre_qkv = nullptr, *pre_att = nullptr, *pre_hid = nullptr;   // batched prompt prefill (decoder.hip), kPrefillRows rows
+  static constexpr int kPrefillRows = 2048;
   int32_t* tok_buf = nullptr;                     // [max_prefixes][max_steps]
   struct PKey { int N, P, steps; bool operator<(const PKey& o) const { return N != o.N ? N < o.N : (P != o.P ? P < o.P : steps < o.steps); } };
   // prompted-decode graphs, keyed by (rows, prompt positions, steps).  The prompt length follows the hard prompt of every batch,
@@ -719,6 +722,8 @@ int pio_create(const pio_config* cfg, pio_handle* out) {
   c->Dout = cfg->vit_out_dim > 0 ? cfg->vit_out_dim : cfg->embed_dim;
   const char* ng = getenv("PIO_NO_GRAPH");
   c->use_graph = !(ng && ng[0] == '1');
+  const char* pf = getenv("PIO_DEC_PREFILL");
+  c->batched_prefill = !(pf && pf[0] == '0');
   hipError_t e = hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return fail(PIO_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
   *out = c;
@@ -735,6 +740,7 @@ int pio_clone_decoder(pio_handle src, pio_handle* out) {
   c->n = src->n; c->n2 = src->n2; c->T = src->T; c->Tp = src->Tp; c->Tk = src->Tk; c->G = src->G; c->D = src->D;
   c->Kpe = src->Kpe; c->Kpad = src->Kpad; c->H = src->H; c->op = src->op; c->Dout = src->Dout;
   c->use_graph = src->use_graph;
+  c->batched_prefill = src->batched_prefill;
   // borrowed, read-only: the decoder's weights (freed by the owner only)
   c->clip_w = src->clip_w; c->clip_b = src->clip_b; c->wte = src->wte; c->wpe = src->wpe;
   c->head_w = src->head_w; c->head_c = src->head_c; c->head_d = src->head_d;
@@ -1416,6 +1422,14 @@ int pio_viecap_decode(pio_handle c, const float* cont, const int32_t* tokens, in
     if ((rc = c->dmalloc(&c->prompt_buf, (size_t)c->cfg.max_prefixes * c->cfg.max_steps * E))) return rc;
     if ((rc = c->dmalloc(&c->tok_buf, (size_t)c->cfg.max_prefixes * c->cfg.max_steps))) return rc;
   }
+  const bool batched_prefill = c->batched_prefill;
+  if (batched_prefill && !c->pre_x) {                 // workspace of the batched prompt prefill: 2 048 rows (56 MB)
+    const size_t R = pio_context::kPrefillRows;
+    if ((rc = c->dmalloc(&c->pre_x, R * E))) return rc;
+    if ((rc = c->dmalloc(&c->pre_qkv, R * 3 * E))) return rc;
+    if ((rc = c->dmalloc(&c->pre_att, R * E))) return rc;
+    if ((rc = c->dmalloc(&c->pre_hid, R * 4 * E))) return rc;
+  }
   if (Lt > 0) HIP_OK(hipMemcpyAsync(c->tok_buf, tokens, (size_t)N * Lt * 4, hipMemcpyDeviceToDevice, s));
   HIP_OK(launch_build_prompt(cont, c->tok_buf, c->wte, N, Lc, Lt, E, c->cfg.dec_vocab, soft_first, c->prompt_buf, s));
   DecoderArgs a;
@@ -1426,6 +1440,7 @@ int pio_viecap_decode(pio_handle c, const float* cont, const int32_t* tokens, in
   a.kcache = c->kcache; a.vcache = c->vcache; a.max_steps = c->cfg.max_steps; a.logits = c->logits; a.ids = c->ids_buf; a.logprob = nullptr;
   a.head_w16 = c->head_w16; a.head_w16_unscale = c->head_w16_unscale; a.head_bound_coef = c->head_bound_coef;
   a.xh = c->dec_xh; a.lm_stats = c->lm_stats; a.lm_gmax = c->lm_gmax; a.pos_base = P - 1;
+  if (batched_prefill) { a.pre_x = c->pre_x; a.pre_qkv = c->pre_qkv; a.pre_att = c->pre_att; a.pre_hid = c->pre_hid; a.pre_rows = pio_context::kPrefillRows; }
   HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, DEC_SPLITK_COUNTERS * sizeof(unsigned), s));
   if (c->use_graph) {
     const pio_context::PKey key{N, P, steps};

@@ -413,14 +413,19 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? PIO_DEC_GEMM_WAVES : 1) void k
 //            pass are in flight at once; 3 shuffles finish the dot product.
 //   output : thread (c4 = tid % (hd/4), jg = tid / (hd/4)) accumulates 4 channels over keys j = jg (mod NJ);
 //            the NJ partial sums meet in LDS.
+// grid.y > 1 (batched prompt prefill, dec_prefill_layers): workgroup (x, y) handles position pos0 + y of prefix n, whose activations are
+// row n * rows_per_n + y of qkv / att; the keys and values of ALL those positions have been appended by k_kv_append before the launch
+// (the workgroup's own append below then rewrites the values that are there).  Same loads, same order per (prefix, head, position).
 __global__ __launch_bounds__(256) void k_dec_attention(const float* __restrict__ qkv, float* kcache, float* vcache,
-                                                       int E, int heads, int pos, int max_steps, float* att) {
+                                                       int E, int heads, int pos0, int max_steps, float* att, int rows_per_n) {
   __shared__ float s_sc[256];
   __shared__ __attribute__((aligned(16))) float s_o[5][256];
   const int n = blockIdx.x / heads, h = blockIdx.x - n * heads;
+  const int pos = pos0 + (int)blockIdx.y;
+  const size_t row = (size_t)n * rows_per_n + blockIdx.y;
   const int tid = threadIdx.x;
   const int hd = E / heads;                      // 192; multiple of 32
-  const float* q = qkv + (size_t)n * 3 * E + h * hd;
+  const float* q = qkv + row * 3 * E + h * hd;
   const float* kn = q + E;
   const float* vn = q + 2 * E;
   float* kc = kcache + ((size_t)n * max_steps) * E + h * hd;
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(256) void k_dec_attention(const float* __restrict__
   if (tid < hd) {
     float o = 0.f;
     for (int g = 0; g < NJ; ++g) o += s_o[g][tid];
-    att[(size_t)n * E + h * hd + tid] = o;
+    att[row * E + h * hd + tid] = o;
   }
 }
 
@@ -1884,7 +1889,7 @@ static hipError_t dec_layers_step(const DecoderArgs& a, int pos, hipStream_t s) 
     float* kc = a.kcache + (size_t)l * N * a.max_steps * E;
     float* vc = a.vcache + (size_t)l * N * a.max_steps * E;
     PIO_TRY((dec_gemm<DE_STORE, 1>(w.attn_w, a.x, N, 3 * E, E, w.attn_d, a.qkv, nullptr, w.attn_c, a.eps, nullptr, nullptr, s, w.attn_ws, w.attn_un)));
-    hipLaunchKernelGGL(k_dec_attention, dim3(N * a.heads), dim3(256), 0, s, a.qkv, kc, vc, E, a.heads, pos, a.max_steps, a.att);
+    hipLaunchKernelGGL(k_dec_attention, dim3(N * a.heads), dim3(256), 0, s, a.qkv, kc, vc, E, a.heads, pos, a.max_steps, a.att, 1);
     PIO_TRY((dec_gemm<DE_RESID, 0>(w.proj_w, a.att, N, E, E, w.proj_b, a.x, nullptr, nullptr, 0.f, nullptr, nullptr, s)));
     PIO_TRY((dec_gemm<DE_GELU, 1>(w.fc_w, a.x, N, 4 * E, E, w.fc_d, a.hid, nullptr, w.fc_c, a.eps, nullptr, nullptr, s, w.fc_ws, w.fc_un)));
     PIO_TRY((dec_gemm<DE_RESID, 0>(w.fc2_w, a.hid, N, E, 4 * E, w.fc2_b, a.x, nullptr, nullptr, 0.f, a.splitk_ws, a.splitk_cnt, s, w.fc2_ws, w.fc2_un)));
@@ -2008,12 +2013,77 @@ hipError_t launch_lm_score(const DecoderArgs& a, const int32_t* tokens, const in
   return hipGetLastError();
 }
 
+// ---- batched prompt prefill (round 5).  The P prompt positions of a prefix do not depend on each other through anything but the key /
+// value cache, so the layer GEMMs take all N * P rows at once (128 rows per launch on the exact fp32 kernels: no split-fp16 operands here)
+// instead of P passes over N rows: per layer ceil(N P / 128) * 4 + 2 launches instead of 5 P (config 5: 16 prefixes x ~30 prompt
+// positions x 12 layers = 1 800 launches of the 5 600 a ViECap caption batch took).  Rows are [n][p]; the attention of position p reads
+// the cache, which k_kv_append fills for every position first.  The sums of a GEMM row are those of k_dec_gemm_b instead of k_dec_gemm
+// (another order of the same exact fp32 products: rounding-level differences in the cache, ids held to the reference's fixtures by
+// tests/test_gpu_viecap.py).
+__global__ __launch_bounds__(256) void k_dec_prompt_x_all(const float* __restrict__ prompt, const float* __restrict__ wpe, int P, int E, float* x) {
+  const int n = blockIdx.x, p = blockIdx.y;
+  const size_t r = (size_t)n * P + p;
+  for (int d = threadIdx.x; d < E; d += 256) x[r * E + d] = prompt[r * E + d] + wpe[(size_t)p * E + d];
+}
+__global__ __launch_bounds__(192) void k_kv_append(const float* __restrict__ qkv, float* kcache, float* vcache, int P, int max_steps, int E) {
+  const int n = blockIdx.x, p = blockIdx.y;
+  const float4* src = (const float4*)(qkv + ((size_t)n * P + p) * 3 * E);
+  float4* kc = (float4*)(kcache + ((size_t)n * max_steps + p) * E);
+  float4* vc = (float4*)(vcache + ((size_t)n * max_steps + p) * E);
+  for (int d = threadIdx.x; d < E / 4; d += 192) { kc[d] = src[E / 4 + d]; vc[d] = src[E / 2 + d]; }
+}
+__global__ __launch_bounds__(256) void k_dec_last_rows(const float* __restrict__ xp, int P, int E, float* x) {
+  const int n = blockIdx.x;
+  for (int d = threadIdx.x; d < E; d += 256) x[(size_t)n * E + d] = xp[((size_t)n * P + P - 1) * E + d];
+}
+static hipError_t dec_prefill_layers(const DecoderArgs& a, int n0, int gN, int P, hipStream_t s) {
+  const int E = a.E, R = gN * P;
+  for (int l = 0; l < a.layers; ++l) {
+    const DecLayerW& w = a.layer[l];
+    float* kc = a.kcache + ((size_t)l * a.N + n0) * a.max_steps * E;
+    float* vc = a.vcache + ((size_t)l * a.N + n0) * a.max_steps * E;
+    for (int r0 = 0; r0 < R; r0 += 128) {
+      const int rows = R - r0 < 128 ? R - r0 : 128;
+      PIO_TRY((dec_gemm<DE_STORE, 1>(w.attn_w, a.pre_x + (size_t)r0 * E, rows, 3 * E, E, w.attn_d, a.pre_qkv + (size_t)r0 * 3 * E, nullptr, w.attn_c,
+                                     a.eps, nullptr, nullptr, s)));
+    }
+    hipLaunchKernelGGL(k_kv_append, dim3(gN, P), dim3(192), 0, s, a.pre_qkv, kc, vc, P, a.max_steps, E);
+    hipLaunchKernelGGL(k_dec_attention, dim3(gN * a.heads, P), dim3(256), 0, s, a.pre_qkv, kc, vc, E, a.heads, 0, a.max_steps, a.pre_att, P);
+    for (int r0 = 0; r0 < R; r0 += 128) {
+      const int rows = R - r0 < 128 ? R - r0 : 128;
+      PIO_TRY((dec_gemm<DE_RESID, 0>(w.proj_w, a.pre_att + (size_t)r0 * E, rows, E, E, w.proj_b, a.pre_x + (size_t)r0 * E, nullptr, nullptr, 0.f,
+                                     nullptr, nullptr, s)));
+    }
+    for (int r0 = 0; r0 < R; r0 += 128) {
+      const int rows = R - r0 < 128 ? R - r0 : 128;
+      PIO_TRY((dec_gemm<DE_GELU, 1>(w.fc_w, a.pre_x + (size_t)r0 * E, rows, 4 * E, E, w.fc_d, a.pre_hid + (size_t)r0 * 4 * E, nullptr, w.fc_c, a.eps,
+                                    nullptr, nullptr, s)));
+    }
+    for (int r0 = 0; r0 < R; r0 += 128) {
+      const int rows = R - r0 < 128 ? R - r0 : 128;
+      PIO_TRY((dec_gemm<DE_RESID, 0>(w.fc2_w, a.pre_hid + (size_t)r0 * 4 * E, rows, E, 4 * E, w.fc2_b, a.pre_x + (size_t)r0 * E, nullptr, nullptr, 0.f,
+                                     a.splitk_ws, a.splitk_cnt, s)));
+    }
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_decode_prompted(const DecoderArgs& a, const float* prompt, int P, hipStream_t s) {
   const bool filtered = PIO_LMHEAD_FILTER && a.logprob == nullptr && a.head_w16 != nullptr;
   if (P < 1 || a.steps < 1 || a.pos_base != P - 1 || !dec_args_ok(a, filtered, P + a.steps - 1)) return hipErrorInvalidValue;
-  for (int pos = 0; pos < P; ++pos) {
-    hipLaunchKernelGGL(k_dec_prompt_x, dim3(a.N), dim3(256), 0, s, prompt, a.wpe, P, pos, a.E, a.x);
-    PIO_TRY(dec_layers_step(a, pos, s));
+  if (a.pre_x != nullptr && P > 1 && P <= a.pre_rows) {
+    const int gmax = a.pre_rows / P;                  // prefixes whose prompts fit the prefill workspace at once
+    for (int n0 = 0; n0 < a.N; n0 += gmax) {
+      const int gN = a.N - n0 < gmax ? a.N - n0 : gmax;
+      hipLaunchKernelGGL(k_dec_prompt_x_all, dim3(gN, P), dim3(256), 0, s, prompt + (size_t)n0 * P * a.E, a.wpe, P, a.E, a.pre_x);
+      PIO_TRY(dec_prefill_layers(a, n0, gN, P, s));
+      hipLaunchKernelGGL(k_dec_last_rows, dim3(gN), dim3(256), 0, s, a.pre_x, P, a.E, a.x + (size_t)n0 * a.E);
+    }
+  } else {
+    for (int pos = 0; pos < P; ++pos) {
+      hipLaunchKernelGGL(k_dec_prompt_x, dim3(a.N), dim3(256), 0, s, prompt, a.wpe, P, pos, a.E, a.x);
+      PIO_TRY(dec_layers_step(a, pos, s));
+    }
   }
   for (int step = 0; step < a.steps; ++step) {
     PIO_TRY(dec_head_step(a, step, filtered, s));            // -> ids[.][step], x = wte[id] + wpe[P + step]

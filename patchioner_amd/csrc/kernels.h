@@ -210,6 +210,9 @@ struct DecoderArgs {
   int32_t* ids;      // [N][steps]
   float* logprob;    // [N][steps] or null
   int pos_base = 0;  // position of the input that produces ids[.][0] (0: the DeCap prefix; P - 1 after a P-position prompt)
+  // optional workspace of the batched prompt prefill (launch_decode_prompted): pre_rows rows of x / qkv / att / hid; null: position by position
+  float *pre_x = nullptr, *pre_qkv = nullptr, *pre_att = nullptr, *pre_hid = nullptr;
+  int pre_rows = 0;
 };
 hipError_t launch_decode_greedy(const DecoderArgs& a, hipStream_t s);
 // ViECap greedy search: prompt [N][P][E] at positions 0..P-1, then a.steps greedy tokens (a.pos_base = P - 1)

@@ -126,6 +126,26 @@ def test_viecap_pieces_vs_reference_and_oracle(O, golden, case):
         assert (np.isnan(a_) and np.isnan(b_)) or abs(a_ - b_) <= 5e-4 * abs(b_), (got_r, want_r)
 
 
+def test_viecap_batched_prompt_prefill_gives_the_ids_of_the_position_by_position_path(case, monkeypatch):
+    """Round 5: the prompt of a ViECap decode goes through the layers as ONE batch of N x P rows (decoder.hip: dec_prefill_layers: the layer
+    GEMMs on 128 rows per launch, the keys / values of every position appended first) instead of P passes over N rows.  Same products,
+    another order of the fp32 sums inside a GEMM row, so the cache differs at rounding level; the ids of both paths are held to each
+    other here (32 prefixes with prompts of different lengths, padded as the reference pads them: pad id 0, no mask) and, in
+    test_viecap_pieces_vs_reference_and_oracle, to the reference's own fixture.  PIO_DEC_PREFILL is read when an engine is created."""
+    w, tok, ents, emb, x = case
+    c = gc.VIECAP
+    feats = torch.cat([x, gc.randn(909, 26, c["C"])]).cuda()
+    ids = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PIO_DEC_PREFILL", mode)
+        m = _model(_viecap_cfg(w, tok, ents, emb, c["C"]), max_batch=4, max_prefixes=32)
+        caps = m.caption_tokens(feats.clone())
+        ids[mode] = (m.viecap.last_ids.cpu().clone(), m.viecap.last_prompt_tokens.clone(), caps)
+        m.engine.close()
+    assert torch.equal(ids["1"][1], ids["0"][1]) and ids["1"][1].shape[0] == 32
+    assert torch.equal(ids["1"][0], ids["0"][0]) and ids["1"][2] == ids["0"][2]
+
+
 def test_viecap_soft_prompt_only_and_routing_through_forward(O, case):
     """using_hard_prompt False (the soft prompt alone) against the oracle, and forward(): cls + trace captions come from the head."""
     w, tok, ents, emb, x = case
