@@ -702,9 +702,12 @@ static hipError_t launch_roll_one(const GemmArgs& a, hipStream_t s) {
   // decode kernels of the other streams, which otherwise find none while a persistent GEMM is resident.  Measured: isolated qkv
   // 81.1 against 82.2 us, fc1 123.5 against 123.9; pipelined throughput unchanged (8.19 against 8.20 k captions/s).
   static const bool balanced = [] { const char* e = getenv("PIO_ROLL_BALANCED"); return e == nullptr || atoi(e) != 0; }();
+  // PIO_ROLL_MAX_GRID (diagnostic, round 5): fewer persistent workgroups than CUs, so that two streams' GEMMs can sit side by side on
+  // the chip (tools/microbench/r5_two_streams.sh)
+  static const int max_grid = [] { const char* e = getenv("PIO_ROLL_MAX_GRID"); const int v = e ? atoi(e) : 0; return v > 0 && v < ROLL_GRID ? v : ROLL_GRID; }();
   const int ntiles = ceil_div(a.M, TM) * (a.N / TN);
-  const int rounds = ceil_div(ntiles, ROLL_GRID);
-  const int grid = balanced ? ceil_div(ntiles, rounds) : ROLL_GRID;
+  const int rounds = ceil_div(ntiles, max_grid);
+  const int grid = balanced ? ceil_div(ntiles, rounds) : max_grid;
   hipLaunchKernelGGL((k_vit_gemm_roll<T, EPI>), dim3(grid), dim3(512), LDS_BYTES, s, a);
   return hipGetLastError();
 }

@@ -20,10 +20,13 @@ run "decodes 2" -- --decode-streams 2 &&
 run "decodes 4" -- --decode-streams 4 &&
 run "decodes 5" -- --decode-streams 5 &&
 run "4 per launch" -- --vit-batches 4 &&
-run "8 per launch" -- --vit-batches 8 &&
+run "8 per launch (128 images)" -- --vit-batches 8 &&
+run "10 per launch (160 images)" -- --vit-batches 10 &&
+run "10 per launch, 10 batches per decode (160 prefixes)" -- --vit-batches 10 --in-flight 10 &&
 run "default again" -- &&
 run "6 batches per decode" -- --in-flight 6 &&
 run "4 batches per decode" -- --in-flight 4 &&
 run "no rolling gemm" PIO_GEMM_ROLL_MIN_TILES=1000000 -- &&
+run "residual GEMMs on the 128-wide kernel" PIO_GEMM_RRES_MIN_TILES=0 -- &&
 run "exact fp32 projection" PIO_PROJECT_EXACT=1 --
 cat gpurun_out/sweep.log
