@@ -348,6 +348,9 @@ def main():
     S = max(1, args.stage_streams)
     VB = max(1, args.vit_batches) if args.mode == "group" and P > 1 else 1       # a ViT launch may feed the tail of one decode group and the head of the next
     DS = max(1, args.decode_streams)
+    # the pipeline is told the length of the stream (run(..., total=K): the last decode groups are cut at the last ViT launch);
+    # PIO_BENCH_END_AWARE=0 feeds it as an endless source would
+    END_AWARE = os.environ.get("PIO_BENCH_END_AWARE", "1") != "0"
     VB_BIG = 10          # the second launch size measured beside the default (`vit_launch_160`): 160 images per ViT launch
     models = build_models(local, P if args.mode == "streams" else S,
                           max_prefixes=min(256, max(64, BATCH * P)) if args.mode == "group" else 64,
@@ -379,7 +382,7 @@ def main():
             return outs, ids
         if pipe is not None:
             caps = seen = ids = None
-            for caps in pipe.run((imgs, traces) for _ in range(n)):
+            for caps in pipe.run(((imgs, traces) for _ in range(n)), total=n if END_AWARE else None):
                 if pipe.last_ids is not seen:          # a new group was decoded: the path's only exchange, its ids
                     seen = pipe.last_ids
                     ids = pdist.all_gather_equal_ids(seen)
@@ -410,7 +413,7 @@ def main():
         # untimed: every decode engine captures its graphs (a full group and the last, partial one) before the clock starts
         prime = torch.zeros(BATCH * P, 768, device="cuda")
         for eng in pipe.decode_engines:
-            for rows in sorted({BATCH * P, BATCH * (args.steps % P)} - {0}):
+            for rows in sorted({BATCH * P} | {BATCH * k for k in (pipe.plan_groups(args.steps) if END_AWARE else [args.steps % P])} - {0}):
                 eng.decode_greedy(prime[:rows], steps=pipe.steps)
         del prime
     fence()
@@ -498,12 +501,17 @@ def main():
 
         def run10(n):
             seen = None
-            for _ in pipe10.run((imgs, traces) for _ in range(n)):
+            for _ in pipe10.run(((imgs, traces) for _ in range(n)), total=n if END_AWARE else None):
                 if pipe10.last_ids is not seen:
                     seen = pipe10.last_ids
                     pdist.all_gather_equal_ids(seen)
         import math
         run10(math.lcm(P, VB_BIG))
+        prime = torch.zeros(BATCH * P, 768, device="cuda")       # untimed: the decode graphs of every group size of the timed run
+        for eng in pipe10.decode_engines:
+            for rows in sorted({BATCH * k for k in (pipe10.plan_groups(args.steps) if END_AWARE else [P, args.steps % P])} - {0}):
+                eng.decode_greedy(prime[:rows], steps=pipe10.steps)
+        del prime
         fence()
         t10 = time.perf_counter()
         run10(args.steps)

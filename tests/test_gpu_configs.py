@@ -175,6 +175,8 @@ def test_grouped_decode_pipeline_matches_synchronous_forward():
     for gb, vb in ((3, 5), (5, 2), (2, 7)):
         pipe = TraceCaptionPipeline(m, group_batches=gb, vit_batches=vb, decode_clones=1)
         assert list(pipe.run((imgs, None) for imgs, _ in batches)) == want, (gb, vb)
+        # the source's length known (run(..., total=): the last groups are cut at the last ViT launch): the same captions
+        assert list(pipe.run(((imgs, None) for imgs, _ in batches), total=len(batches))) == want, (gb, vb)
         pipe.close()
     # CU-masked streams (pio_stream_create): same captions; close() releases them and the pipeline stays usable
     pipe = TraceCaptionPipeline(m, group_batches=4, stage_cus=192, decode_cus=64)

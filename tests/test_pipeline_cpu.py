@@ -95,3 +95,40 @@ def test_eager_first_group_keeps_order_and_never_overflows():
     p._decode = lambda g: (sizes_decoded.append(len(g.counts)), dec(g))[1]
     got = [c[0] for c in p.run((torch.empty(16, 1), i) for i in range(20))]
     assert got == list(range(20)) and sizes_decoded[0] == 5 and sum(sizes_decoded) == 20
+
+
+def test_known_length_cuts_the_last_groups_at_the_last_vit_launch():
+    """run(..., total=N): the open group closes where the last ViT launch begins, so only that launch's own batches wait for it
+    (bench.py: 20 batches, 5 per launch, 8 per decode -> groups of 8 / 7 / 5 instead of 8 / 8 / 4); plan_groups says the same
+    sizes ahead of time; every batch still comes back once, in order, for any total (right, wrong or absent)."""
+    def sizes_of(gb, vb, n, total, ng=4, cap=128):
+        p, launches = _make(gb, vb, ng, cap=cap)
+        decoded, dec = [], p._decode
+        p._decode = lambda g: (decoded.append(len(g.counts)), dec(g))[1]
+        got = [c[0] for c in p.run(((torch.empty(16, 1), i) for i in range(n)), total=total)]
+        assert got == list(range(n)), (gb, vb, n, total, got)
+        return decoded, launches, p
+
+    decoded, launches, p = sizes_of(8, 5, 20, 20)
+    assert decoded == [8, 7, 5] and launches == [5] * 4 and p.plan_groups(20) == [8, 7, 5]
+    assert sizes_of(8, 5, 20, None)[0] == [8, 8, 4]
+    assert sizes_of(8, 5, 128, 128)[0] == [8] * 16         # the cut would make a 17th decode: not taken
+    assert sizes_of(8, 10, 20, 20)[0] == [8, 8, 4]         # ... 8 / 2 / 8 / 2 here
+    assert sizes_of(8, 5, 21, 21)[0] == [8, 8, 5] and sizes_of(8, 5, 13, 13)[0] == [8, 5] and sizes_of(8, 5, 10, 10)[0] == [5, 5]
+    for gb, vb, n in itertools.product((1, 2, 3, 4, 8), (1, 2, 4, 5, 8, 10), (0, 1, 4, 5, 6, 13, 20, 21, 40)):
+        decoded, launches, p = sizes_of(gb, vb, n, n)
+        assert decoded == p.plan_groups(n) and sum(launches) == n, (gb, vb, n, decoded)
+        if n:
+            # never a decode more than without the total; where the cut is taken, no group but the last launch's own reaches into it
+            assert len(decoded) == -(-n // gb), (gb, vb, n, decoded)
+            if p._last_launch_start(n):
+                assert p._last_launch_start(n) == vb * ((n - 1) // vb) and p._last_launch_start(n) in list(itertools.accumulate(decoded))
+        for wrong in (n - 3, n + 7):                       # a wrong total costs time, not captions
+            sizes_of(gb, vb, n, wrong if wrong > 0 else None)
+    # ragged batches (groups also close on their prefix capacity): order and completeness with a total
+    rnd = random.Random(11)
+    for gb, vb, ng in itertools.product((2, 3, 8), (1, 3, 5), (2, 4)):
+        sizes = [rnd.choice((1, 3, 8, 16, 16, 16)) for _ in range(rnd.randint(0, 23))]
+        p, _ = _make(gb, vb, ng)
+        got = [c[0] for c in p.run(((torch.empty(n, 1), i) for i, n in enumerate(sizes)), total=len(sizes))]
+        assert got == list(range(len(sizes))), (gb, vb, ng, sizes, got)
