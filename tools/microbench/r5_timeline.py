@@ -23,12 +23,13 @@ def main():
     torch.cuda.set_device(0)
     torch.set_grad_enabled(False)
     from patchioner_amd.pipeline import TraceCaptionPipeline
-    model = bench.build_models(0, 1, max_prefixes=128, max_batch=16 * max(VB, 10))[0]
+    GB = int(os.environ.get("PIO_TL_GROUP", "8"))
+    model = bench.build_models(0, 1, max_prefixes=16 * GB, max_batch=16 * max(VB, 10))[0]
     imgs, traces = bench.make_inputs()
-    pipe = TraceCaptionPipeline(model, group_batches=8, vit_batches=VB, decode_clones=clones)
-    prime = torch.zeros(128, 768, device="cuda")
+    pipe = TraceCaptionPipeline(model, group_batches=GB, vit_batches=VB, decode_clones=clones)
+    prime = torch.zeros(16 * GB, 768, device="cuda")
     for eng in pipe.decode_engines:
-        for k in range(1, 9):
+        for k in range(1, GB + 1):
             eng.decode_greedy(prime[:16 * k], steps=pipe.steps)
     marks = []
     stage0, decode0 = pipe._stage, pipe._decode
