@@ -119,6 +119,7 @@ struct pio_context {
   std::map<GraphKey, hipGraphExec_t> graphs;
   hipStream_t capture_stream = nullptr;
   bool use_graph = true;
+  bool lm_tail = false;                           // <= 16 prefixes: the arg-max filter as the ticketed tail of the LM head kernel (PIO_LM_TAIL=1 at pio_create; measured slower, decoder.hip)
   bool batched_prefill = true;                    // prompted decodes take their prompt through the layers in one batch (PIO_DEC_PREFILL=0 at pio_create: position by position)
   // inversion
   float *A_pinv = nullptr, *inv_b = nullptr;
@@ -516,7 +517,7 @@ int alloc_decoder_workspaces(pio_context* c) {
   if ((rc = c->dmalloc(&c->datt, N * E, true))) return rc;
   if ((rc = c->dmalloc(&c->dhid, N * 4 * E, true))) return rc;
   if ((rc = c->dmalloc(&c->splitk_ws, (size_t)DEC_SPLITK_COUNTERS * 4 * 8 * 256, true))) return rc;   // tiles x 4 k-slices x 8 (column, row) group pairs
-  if ((rc = c->dmalloc(&c->splitk_cnt, DEC_SPLITK_COUNTERS, true))) return rc;
+  if ((rc = c->dmalloc(&c->splitk_cnt, DEC_TICKET_WORDS, true))) return rc;
   if ((rc = c->dmalloc(&c->kcache, (size_t)L * N * S * E, true))) return rc;
   if ((rc = c->dmalloc(&c->vcache, (size_t)L * N * S * E, true))) return rc;
   if ((rc = c->dmalloc(&c->logits, N * (size_t)round_up(V, 64), true))) return rc;
@@ -724,6 +725,8 @@ int pio_create(const pio_config* cfg, pio_handle* out) {
   c->use_graph = !(ng && ng[0] == '1');
   const char* pf = getenv("PIO_DEC_PREFILL");
   c->batched_prefill = !(pf && pf[0] == '0');
+  const char* lt = getenv("PIO_LM_TAIL");
+  c->lm_tail = lt && lt[0] == '1';
   hipError_t e = hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return fail(PIO_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
   *out = c;
@@ -741,6 +744,7 @@ int pio_clone_decoder(pio_handle src, pio_handle* out) {
   c->Kpe = src->Kpe; c->Kpad = src->Kpad; c->H = src->H; c->op = src->op; c->Dout = src->Dout;
   c->use_graph = src->use_graph;
   c->batched_prefill = src->batched_prefill;
+  c->lm_tail = src->lm_tail;
   // borrowed, read-only: the decoder's weights (freed by the owner only)
   c->clip_w = src->clip_w; c->clip_b = src->clip_b; c->wte = src->wte; c->wpe = src->wpe;
   c->head_w = src->head_w; c->head_c = src->head_c; c->head_d = src->head_d;
@@ -1222,12 +1226,12 @@ int pio_decode_greedy(pio_handle c, const float* prefix, int32_t N, int32_t step
   a.N = N; a.steps = steps; a.E = E; a.heads = c->cfg.dec_heads; a.layers = c->cfg.dec_layers; a.vocab = c->cfg.dec_vocab;
   a.prefix_size = PS; a.eps = c->cfg.dec_ln_eps; a.prefix = c->prefix_buf; a.clip_w = c->clip_w; a.clip_b = c->clip_b;
   a.wte = c->wte; a.wpe = c->wpe; a.head_w = c->head_w; a.head_c = c->head_c; a.head_d = c->head_d; a.layer = c->dl.data();
-  a.x = c->dx; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.splitk_ws = c->splitk_ws; a.splitk_cnt = c->splitk_cnt; a.kcache = c->kcache; a.vcache = c->vcache;
+  a.x = c->dx; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.splitk_ws = c->splitk_ws; a.splitk_cnt = c->splitk_cnt; a.lm_tail = c->lm_tail ? 1 : 0; a.kcache = c->kcache; a.vcache = c->vcache;
   a.max_steps = c->cfg.max_steps; a.logits = c->logits; a.ids = c->ids_buf; a.logprob = logprob ? c->logprob_buf : nullptr;
   a.head_w16 = c->head_w16; a.head_w16_unscale = c->head_w16_unscale; a.head_bound_coef = c->head_bound_coef;
   a.xh = c->dec_xh; a.lm_stats = c->lm_stats; a.lm_gmax = c->lm_gmax;
   HIP_OK(hipMemcpyAsync(c->prefix_buf, prefix, (size_t)N * PS * 4, hipMemcpyDeviceToDevice, s));
-  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, DEC_SPLITK_COUNTERS * sizeof(unsigned), s));   // tickets start at zero whatever happened before
+  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, DEC_TICKET_WORDS * sizeof(unsigned), s));   // tickets start at zero whatever happened before
   // algorithmic work of a KV-cached decode: per token 4 layers x 12 E^2 MACs + the tied LM head;
   // bytes = every fp32 weight read once per step
   const double layer_params = (double)c->cfg.dec_layers * 12.0 * E * E, head_params = (double)c->cfg.dec_vocab * E;
@@ -1317,11 +1321,11 @@ int pio_lm_score(pio_handle c, const int32_t* tokens, const int32_t* lens, int32
   a.N = N; a.steps = 1; a.E = c->cfg.dec_embd; a.heads = c->cfg.dec_heads; a.layers = c->cfg.dec_layers; a.vocab = c->cfg.dec_vocab;
   a.prefix_size = c->cfg.prefix_size; a.eps = c->cfg.dec_ln_eps; a.prefix = nullptr; a.clip_w = nullptr; a.clip_b = nullptr;
   a.wte = c->wte; a.wpe = c->wpe; a.head_w = c->head_w; a.head_c = c->head_c; a.head_d = c->head_d; a.layer = c->dl.data();
-  a.x = c->dx; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.splitk_ws = c->splitk_ws; a.splitk_cnt = c->splitk_cnt;
+  a.x = c->dx; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.splitk_ws = c->splitk_ws; a.splitk_cnt = c->splitk_cnt; a.lm_tail = c->lm_tail ? 1 : 0;
   a.kcache = c->kcache; a.vcache = c->vcache; a.max_steps = c->cfg.max_steps; a.logits = c->logits; a.ids = c->ids_buf; a.logprob = nullptr;
   a.head_w16 = c->head_w16; a.head_w16_unscale = c->head_w16_unscale; a.head_bound_coef = c->head_bound_coef;
   a.xh = c->dec_xh; a.lm_stats = c->lm_stats; a.lm_gmax = c->lm_gmax; a.pos_base = 0;
-  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, DEC_SPLITK_COUNTERS * sizeof(unsigned), s));
+  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, DEC_TICKET_WORDS * sizeof(unsigned), s));
   HIP_OK(launch_lm_score(a, tokens, lens, Lmax, nll, s));
   return PIO_OK;
 }
@@ -1332,7 +1336,7 @@ static DecoderArgs lm_args(pio_context* c, int N) {
   a.N = N; a.steps = 1; a.E = c->cfg.dec_embd; a.heads = c->cfg.dec_heads; a.layers = c->cfg.dec_layers; a.vocab = c->cfg.dec_vocab;
   a.prefix_size = c->cfg.prefix_size; a.eps = c->cfg.dec_ln_eps; a.prefix = nullptr; a.clip_w = nullptr; a.clip_b = nullptr;
   a.wte = c->wte; a.wpe = c->wpe; a.head_w = c->head_w; a.head_c = c->head_c; a.head_d = c->head_d; a.layer = c->dl.data();
-  a.x = c->dx; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.splitk_ws = c->splitk_ws; a.splitk_cnt = c->splitk_cnt;
+  a.x = c->dx; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.splitk_ws = c->splitk_ws; a.splitk_cnt = c->splitk_cnt; a.lm_tail = c->lm_tail ? 1 : 0;
   a.kcache = c->kcache; a.vcache = c->vcache; a.max_steps = c->cfg.max_steps; a.logits = c->logits; a.ids = c->ids_buf; a.logprob = nullptr;
   a.head_w16 = c->head_w16; a.head_w16_unscale = c->head_w16_unscale; a.head_bound_coef = c->head_bound_coef;
   a.xh = c->dec_xh; a.lm_stats = c->lm_stats; a.lm_gmax = c->lm_gmax; a.pos_base = 0;
@@ -1374,7 +1378,7 @@ int pio_lm_prefill(pio_handle c, const float* embeds, int32_t N, int32_t P, floa
   if ((rc = beam_scratch(c))) return rc;
   hipStream_t s = (hipStream_t)stream;
   const DecoderArgs a = lm_args(c, N);
-  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, DEC_SPLITK_COUNTERS * sizeof(unsigned), s));
+  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, DEC_TICKET_WORDS * sizeof(unsigned), s));
   HIP_OK(launch_lm_prefill(a, embeds, P, c->beam_stats, logp, s));
   return PIO_OK;
 }
@@ -1389,7 +1393,7 @@ int pio_lm_advance(pio_handle c, const int32_t* tokens, const int32_t* src_rows,
   if ((rc = beam_scratch(c))) return rc;
   hipStream_t s = (hipStream_t)stream;
   const DecoderArgs a = lm_args(c, N);
-  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, DEC_SPLITK_COUNTERS * sizeof(unsigned), s));
+  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, DEC_TICKET_WORDS * sizeof(unsigned), s));
   HIP_OK(launch_lm_advance(a, tokens, src_rows, pos, c->beam_k, c->beam_v, c->beam_stats, logp, s));
   return PIO_OK;
 }
@@ -1436,12 +1440,12 @@ int pio_viecap_decode(pio_handle c, const float* cont, const int32_t* tokens, in
   a.N = N; a.steps = steps; a.E = E; a.heads = c->cfg.dec_heads; a.layers = c->cfg.dec_layers; a.vocab = c->cfg.dec_vocab;
   a.prefix_size = c->cfg.prefix_size; a.eps = c->cfg.dec_ln_eps; a.prefix = nullptr; a.clip_w = nullptr; a.clip_b = nullptr;
   a.wte = c->wte; a.wpe = c->wpe; a.head_w = c->head_w; a.head_c = c->head_c; a.head_d = c->head_d; a.layer = c->dl.data();
-  a.x = c->dx; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.splitk_ws = c->splitk_ws; a.splitk_cnt = c->splitk_cnt;
+  a.x = c->dx; a.qkv = c->dqkv; a.att = c->datt; a.hid = c->dhid; a.splitk_ws = c->splitk_ws; a.splitk_cnt = c->splitk_cnt; a.lm_tail = c->lm_tail ? 1 : 0;
   a.kcache = c->kcache; a.vcache = c->vcache; a.max_steps = c->cfg.max_steps; a.logits = c->logits; a.ids = c->ids_buf; a.logprob = nullptr;
   a.head_w16 = c->head_w16; a.head_w16_unscale = c->head_w16_unscale; a.head_bound_coef = c->head_bound_coef;
   a.xh = c->dec_xh; a.lm_stats = c->lm_stats; a.lm_gmax = c->lm_gmax; a.pos_base = P - 1;
   if (batched_prefill) { a.pre_x = c->pre_x; a.pre_qkv = c->pre_qkv; a.pre_att = c->pre_att; a.pre_hid = c->pre_hid; a.pre_rows = pio_context::kPrefillRows; }
-  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, DEC_SPLITK_COUNTERS * sizeof(unsigned), s));
+  HIP_OK(hipMemsetAsync(c->splitk_cnt, 0, DEC_TICKET_WORDS * sizeof(unsigned), s));
   if (c->use_graph) {
     const pio_context::PKey key{N, P, steps};
     auto it = c->pgraphs.find(key);

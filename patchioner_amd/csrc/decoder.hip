@@ -1627,14 +1627,125 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_lmhead_f16(const
   }
 }
 
+// Per row: max of the approximate logits (from the per-16-column group maxima), exact re-evaluation of every column
+// within the bound, next-step input.  Groups whose maximum passes the threshold go to a list in LDS (a handful per
+// row); should more than CAND groups pass, every group is walked instead (same result, slower).
+// One row of the filter: 256 threads.  AGENT: the approximate logits and group maxima were written by other workgroups of THIS launch
+// (k_lmhead_f16_fused<true>): relaxed agent-scope loads read the coherent copy, as in the split-K exchange above.
+template <bool AGENT>
+__device__ __forceinline__ float ld_maybe_agent(const float* p) {
+  if constexpr (AGENT) return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  else return *p;
+}
+template <bool AGENT>
+__device__ __forceinline__ void dec_select_row(const int n, const float4 st, const float* approx, const float* gmax, int V, int Vp, int NG, int NGp,
+                                               const float* xrow, const float* __restrict__ W /*[V][E] LN-folded*/,
+                                               const float* __restrict__ dvec, const float* __restrict__ cvec, int E, int step, int steps,
+                                               const float* __restrict__ wte, const float* __restrict__ wpe, int32_t* ids, float* x, int pos_base) {
+  constexpr int CAND = 512;
+  __shared__ float s_v[4];
+  __shared__ int s_i[4];
+  __shared__ int s_cnt;
+  __shared__ int s_list[CAND];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* a = approx + (size_t)n * Vp;
+  const float* gm = gmax + (size_t)n * NGp;
+  int best_i = 0;
+  if (st.w == st.w) {                                   // finite row (block-uniform)
+    float gv[16];                                       // this thread's group maxima (NG <= 4096), all loads in flight
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int gi = tid + 256 * k;
+      gv[k] = gi < NG ? ld_maybe_agent<AGENT>(gm + gi) : -INFINITY;
+      mx = fmaxf(mx, gv[k]);
+    }
+    if (tid == 0) s_cnt = 0;
+    mx = wave_max(mx);
+    if (lane == 0) s_v[wid] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_v[0], s_v[1]), fmaxf(s_v[2], s_v[3]));
+    const float thr = mx - 2.0f * st.w - 1e-5f * (1.0f + fabsf(mx));
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (gv[k] >= thr) {
+        const int slot = atomicAdd(&s_cnt, 1);
+        if (slot < CAND) s_list[slot] = tid + 256 * k;
+      }
+    __syncthreads();
+    const int cnt = s_cnt;
+    const bool listed = cnt <= CAND;
+    const int ngroups = listed ? cnt : NG;
+    // this row of x, 12 values per lane (every wave keeps its own copy)
+    float4 xr[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xr[i] = *(const float4*)(xrow + (size_t)n * E + 4 * lane + 256 * i);
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = wid; c < ngroups; c += 4) {            // wave-uniform loop over candidate groups
+      const int gi = listed ? s_list[c] : c;
+      const int v = gi * 16 + (lane & 15);
+      const float val = (lane < 16 && v < V) ? ld_maybe_agent<AGENT>(a + v) : -INFINITY;
+      unsigned long long m = __ballot(val >= thr);
+      while (m) {                                       // all lanes evaluate candidate column vc exactly
+        const int vc = gi * 16 + __builtin_ctzll(m);
+        m &= m - 1;
+        const float* wr = W + (size_t)vc * E + 4 * lane;
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const float4 ww = *(const float4*)(wr + 256 * i);
+          sacc = fmaf(xr[i].x, ww.x, sacc); sacc = fmaf(xr[i].y, ww.y, sacc);
+          sacc = fmaf(xr[i].z, ww.z, sacc); sacc = fmaf(xr[i].w, ww.w, sacc);
+        }
+        sacc = wave_sum(sacc);
+        const float exact = st.y * (sacc - st.x * cvec[vc]) + dvec[vc];
+        if (arg_better(exact, vc, bv, bi)) { bv = exact; bi = vc; }
+      }
+    }
+    __syncthreads();
+    if (lane == 0) { s_v[wid] = bv; s_i[wid] = bi; }
+    __syncthreads();
+    bv = s_v[0]; bi = s_i[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (arg_better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
+    best_i = bi < V ? bi : 0;
+  }
+  for (int d = tid; d < E; d += 256) x[(size_t)n * E + d] = wte[(size_t)best_i * E + d] + wpe[(size_t)(pos_base + step + 1) * E + d];
+  if (tid == 0) ids[(size_t)n * steps + step] = best_i;
+}
+
+__global__ __launch_bounds__(256) void k_dec_select_filter(const float* __restrict__ approx, const float* __restrict__ gmax, int V, int Vp,
+                                                           int NG, int NGp, const float* __restrict__ stats,
+                                                           const float* xrow, const float* __restrict__ W /*[V][E] LN-folded*/,
+                                                           const float* __restrict__ dvec, const float* __restrict__ cvec, int E, int step,
+                                                           int steps, const float* __restrict__ wte, const float* __restrict__ wpe,
+                                                           int32_t* ids, float* x, int pos_base) {
+  const int n = blockIdx.x;
+  dec_select_row<false>(n, *(const float4*)(stats + 4 * n), approx, gmax, V, Vp, NG, NGp, xrow, W, dvec, cvec, E, step, steps, wte, wpe, ids, x, pos_base);
+}
+
 // <= 16 prefixes: k_lm_prep folded into the head (one kernel less per step).  Every workgroup recomputes the rows'
 // LayerNorm statistics and fp16 copies (49 KB of x from L2) and keeps ALL of X~ (16 x 768 fp16 = 24 KB, the same
 // chunked, swizzled image as above) in LDS: nothing to stage per chunk, no barrier in the K loop.  Workgroup 0
 // publishes the statistics for k_dec_select_filter.
-__global__ __launch_bounds__(256, 2) void k_lmhead_f16_fused(const uint16_t* __restrict__ W16, const float* __restrict__ x, int N, int V,
+//
+// TAIL (round 5): k_dec_select_filter as the tail of this kernel -- one launch less per step.  Every workgroup stores its approximate
+// logits and group maxima by relaxed agent-scope atomic stores (written through: the split-K exchange's idiom above), drains them, and
+// draws a ticket; the LAST N arrivals each take one row: they wait until the ticket says that every workgroup has arrived (only the last
+// N ever wait, at most N - 1 of them, for workgroups that are running or about to: the grid drains whatever the residency), read
+// the maxima / candidates back by agent-scope loads and run dec_select_row.  The statistics of the row are the workgroup's own (every
+// workgroup computes all 16 rows').  `tk[0]` = ticket, `tk[1]` = rows done; the tail that finishes last re-arms both for the next step.
+// x is read by every workgroup before its ticket and written (the next step's input) only behind the full count.
+struct LmTail {
+  unsigned* tk; const float* W32; int E, step, steps; const float* wte; const float* wpe; int32_t* ids; float* xnext; int pos_base, NG;
+};
+template <bool TAIL>
+__global__ __launch_bounds__(256, 2) void k_lmhead_f16_fused(const uint16_t* __restrict__ W16, const float* x, int N, int V,
                                                              int Vp, float eps, float bound_coef, float* __restrict__ stats,
                                                              const float* __restrict__ dvec, const float* __restrict__ cvec,
-                                                             float w_unscale, float* __restrict__ out, float* __restrict__ gmax, int NGp) {
+                                                             float w_unscale, float* out, float* gmax, int NGp, const LmTail tl) {
   constexpr int K = 768, CH = 64, NCH = K / CH;
   __shared__ __attribute__((aligned(16))) char xs[NCH * 16 * 128];      // [chunk][row][64 fp16], 16-B slots XORed with (row>>1)&7
   __shared__ __attribute__((aligned(16))) float s_st[16][4];
@@ -1721,101 +1832,45 @@ __global__ __launch_bounds__(256, 2) void k_lmhead_f16_fused(const uint16_t* __r
   }
 #undef PIO_WLOAD
 #undef PIO_WWAIT
-  if (blk * 16 >= V) return;
-  const float cj = cvec[jc], dj = dvec[jc];
+  if (blk * 16 < V) {                                 // wave-uniform (the last workgroup's waves past the vocabulary have no columns)
+    const float cj = cvec[jc], dj = dvec[jc];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = 4 * kq + i;
-    const float4 st = *(const float4*)s_st[n];
-    const float v = j < V ? st.y * (acc[i] * (st.z * w_unscale) - st.x * cj) + dj : -INFINITY;
-    if (n < N && j < V) out[(size_t)n * Vp + j] = v;
-    const float gm = row16_max(v);
-    if (li == 0 && n < N) gmax[(size_t)n * NGp + blk] = gm;
-  }
-}
-
-// Per row: max of the approximate logits (from the per-16-column group maxima), exact re-evaluation of every column
-// within the bound, next-step input.  Groups whose maximum passes the threshold go to a list in LDS (a handful per
-// row); should more than CAND groups pass, every group is walked instead (same result, slower).
-__global__ __launch_bounds__(256) void k_dec_select_filter(const float* __restrict__ approx, const float* __restrict__ gmax, int V, int Vp,
-                                                           int NG, int NGp, const float* __restrict__ stats,
-                                                           const float* __restrict__ xrow, const float* __restrict__ W /*[V][E] LN-folded*/,
-                                                           const float* __restrict__ dvec, const float* __restrict__ cvec, int E, int step,
-                                                           int steps, const float* __restrict__ wte, const float* __restrict__ wpe,
-                                                           int32_t* ids, float* x, int pos_base) {
-  constexpr int CAND = 512;
-  __shared__ float s_v[4];
-  __shared__ int s_i[4];
-  __shared__ int s_cnt;
-  __shared__ int s_list[CAND];
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const float4 st = *(const float4*)(stats + 4 * n);
-  const float* a = approx + (size_t)n * Vp;
-  const float* gm = gmax + (size_t)n * NGp;
-  int best_i = 0;
-  if (st.w == st.w) {                                   // finite row (block-uniform)
-    float gv[16];                                       // this thread's group maxima (NG <= 4096), all loads in flight
-    float mx = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int gi = tid + 256 * k;
-      gv[k] = gi < NG ? gm[gi] : -INFINITY;
-      mx = fmaxf(mx, gv[k]);
-    }
-    if (tid == 0) s_cnt = 0;
-    mx = wave_max(mx);
-    if (lane == 0) s_v[wid] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(s_v[0], s_v[1]), fmaxf(s_v[2], s_v[3]));
-    const float thr = mx - 2.0f * st.w - 1e-5f * (1.0f + fabsf(mx));
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      if (gv[k] >= thr) {
-        const int slot = atomicAdd(&s_cnt, 1);
-        if (slot < CAND) s_list[slot] = tid + 256 * k;
-      }
-    __syncthreads();
-    const int cnt = s_cnt;
-    const bool listed = cnt <= CAND;
-    const int ngroups = listed ? cnt : NG;
-    // this row of x, 12 values per lane (every wave keeps its own copy)
-    float4 xr[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) xr[i] = *(const float4*)(xrow + (size_t)n * E + 4 * lane + 256 * i);
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int c = wid; c < ngroups; c += 4) {            // wave-uniform loop over candidate groups
-      const int gi = listed ? s_list[c] : c;
-      const int v = gi * 16 + (lane & 15);
-      const float val = (lane < 16 && v < V) ? a[v] : -INFINITY;
-      unsigned long long m = __ballot(val >= thr);
-      while (m) {                                       // all lanes evaluate candidate column vc exactly
-        const int vc = gi * 16 + __builtin_ctzll(m);
-        m &= m - 1;
-        const float* wr = W + (size_t)vc * E + 4 * lane;
-        float sacc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const float4 ww = *(const float4*)(wr + 256 * i);
-          sacc = fmaf(xr[i].x, ww.x, sacc); sacc = fmaf(xr[i].y, ww.y, sacc);
-          sacc = fmaf(xr[i].z, ww.z, sacc); sacc = fmaf(xr[i].w, ww.w, sacc);
-        }
-        sacc = wave_sum(sacc);
-        const float exact = st.y * (sacc - st.x * cvec[vc]) + dvec[vc];
-        if (arg_better(exact, vc, bv, bi)) { bv = exact; bi = vc; }
+    for (int i = 0; i < 4; ++i) {
+      const int n = 4 * kq + i;
+      const float4 st = *(const float4*)s_st[n];
+      const float v = j < V ? st.y * (acc[i] * (st.z * w_unscale) - st.x * cj) + dj : -INFINITY;
+      const float gm = row16_max(v);
+      if constexpr (TAIL) {
+        if (n < N && j < V) __hip_atomic_store((unsigned*)(out + (size_t)n * Vp + j), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (li == 0 && n < N) __hip_atomic_store((unsigned*)(gmax + (size_t)n * NGp + blk), __float_as_uint(gm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (n < N && j < V) out[(size_t)n * Vp + j] = v;
+        if (li == 0 && n < N) gmax[(size_t)n * NGp + blk] = gm;
       }
     }
-    __syncthreads();
-    if (lane == 0) { s_v[wid] = bv; s_i[wid] = bi; }
-    __syncthreads();
-    bv = s_v[0]; bi = s_i[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w)
-      if (arg_better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
-    best_i = bi < V ? bi : 0;
   }
-  for (int d = tid; d < E; d += 256) x[(size_t)n * E + d] = wte[(size_t)best_i * E + d] + wpe[(size_t)(pos_base + step + 1) * E + d];
-  if (tid == 0) ids[(size_t)n * steps + step] = best_i;
+  if constexpr (TAIL) {
+    __shared__ unsigned s_ticket;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its stores (written through)
+    __syncthreads();
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(tl.tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned total = gridDim.x, t = s_ticket;
+    if (t + (unsigned)N < total) return;                        // not one of the last N arrivals (block-uniform)
+    const int n = (int)(t + (unsigned)N - total);               // 0 .. N - 1 (the host launches this form with N <= gridDim.x)
+    if (tid == 0)
+      while (__hip_atomic_load(tl.tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) __builtin_amdgcn_s_sleep(1);
+    __syncthreads();
+    dec_select_row<true>(n, *(const float4*)s_st[n], out, gmax, V, Vp, tl.NG, NGp, x, tl.W32, dvec, cvec, tl.E, tl.step, tl.steps, tl.wte, tl.wpe, tl.ids,
+                         tl.xnext, tl.pos_base);
+    if (tid == 0) {
+      const unsigned d = __hip_atomic_fetch_add(tl.tk + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d + 1 == (unsigned)N) {                               // every tail has read the full count: re-arm for the next step's launch
+        __hip_atomic_store(tl.tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tl.tk + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 
 template <int RG>
@@ -1844,9 +1899,20 @@ static hipError_t launch_lmhead_filtered(const DecoderArgs& a, int step, hipStre
   hipError_t e;
   const int rg = ceil_div(a.N, 16);
   if (PIO_LMF16_FUSED && rg <= 1) {
-    const int NGp1 = round_up(ceil_div(a.vocab, 16), 64);
-    hipLaunchKernelGGL(k_lmhead_f16_fused, dim3(ceil_div(a.vocab, 64)), dim3(256), 0, s, a.head_w16, a.x, a.N, a.vocab, Vp, a.eps,
-                       a.head_bound_coef, a.lm_stats, a.head_d, a.head_c, a.head_w16_unscale, a.logits, a.lm_gmax, NGp1);
+    const int NGp1 = round_up(ceil_div(a.vocab, 16), 64), NG1 = ceil_div(a.vocab, 16), nwg = ceil_div(a.vocab, 64);
+    if (NG1 > 4096) return hipErrorInvalidValue;
+    // a.lm_tail (PIO_LM_TAIL=1 when the engine is created): the filter as the tail of the head kernel, 21 launches per step instead of 22.
+    // Built for VERDICT r4 and MEASURED SLOWER, so it is off: decode(16) 4.285 against 4.15 ms, decode(1) 3.90 against 3.79 (two alternations on one
+    // box, ids identical) -- the written-through stores, their drain in every workgroup, the ticket and the agent-scope re-reads cost
+    // ~9 us per step where the separate launch costs ~5.8 + its gap.
+    if (a.lm_tail && a.splitk_cnt != nullptr && a.N <= nwg) {
+      const LmTail tl{a.splitk_cnt + DEC_SPLITK_COUNTERS, a.head_w, a.E, step, a.steps, a.wte, a.wpe, a.ids, a.x, a.pos_base, NG1};
+      hipLaunchKernelGGL(k_lmhead_f16_fused<true>, dim3(nwg), dim3(256), 0, s, a.head_w16, a.x, a.N, a.vocab, Vp, a.eps,
+                         a.head_bound_coef, a.lm_stats, a.head_d, a.head_c, a.head_w16_unscale, a.logits, a.lm_gmax, NGp1, tl);
+      return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_lmhead_f16_fused<false>, dim3(nwg), dim3(256), 0, s, a.head_w16, a.x, a.N, a.vocab, Vp, a.eps,
+                       a.head_bound_coef, a.lm_stats, a.head_d, a.head_c, a.head_w16_unscale, a.logits, a.lm_gmax, NGp1, LmTail{});
     e = hipGetLastError();
   } else {
     hipLaunchKernelGGL(k_lm_prep, dim3(a.N), dim3(256), 0, s, a.x, a.E, a.eps, a.head_bound_coef, (_Float16*)a.xh, a.lm_stats);

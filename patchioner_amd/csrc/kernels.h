@@ -181,6 +181,7 @@ struct DecLayerW {
 hipError_t dec_split_weights(const float* W, size_t n, void* out, float* unscale, hipStream_t s);
 static constexpr int DEC_MAX_PREFIXES = 256;       // rows of one greedy decode (ids only; log-probabilities: 64 per call)
 static constexpr int DEC_SPLITK_COUNTERS = 128;    // arrival tickets / slab groups of the in-launch split-K (api.cpp allocates them)
+static constexpr int DEC_TICKET_WORDS = DEC_SPLITK_COUNTERS + 2;   // ... + the LM head's arrival ticket and its tail's done-count (decoder.hip: k_lmhead_f16_fused<true>)
 struct DecoderArgs {
   int N, steps, E, heads, layers, vocab, prefix_size;
   float eps;
@@ -197,7 +198,8 @@ struct DecoderArgs {
   float* vcache;
   int max_steps;
   float* splitk_ws;       // [64 column groups][4 k-slices][4 row groups][256] partial tiles
-  unsigned* splitk_cnt;   // [64] arrival tickets (zero between launches)
+  unsigned* splitk_cnt;   // [DEC_TICKET_WORDS] arrival tickets (zero between launches)
+  int lm_tail;            // <= 16 prefixes: k_dec_select_filter as the ticketed tail of the LM head kernel (off by default: measured slower)
   float* logits; // [ceil(V/16)][N][4] per-workgroup (max, arg-max, sum-exp) partials of the LM head, or the
                  // approximate logits [N][round_up(V, 64)] of the fp16 filter
   // fp16 filter of the LM head (null head_w16: exact head only)

@@ -139,7 +139,7 @@ def test_inline_asm_weight_loads_are_not_touched_before_their_wait(tmp_path):
                     os.path.join(ROOT, "patchioner_amd", "csrc", "decoder.hip"), "-o", str(asm)], check=True)
     text = asm.read_text()
     names = sorted(set(re.findall(r"^(_ZN3pio\d+k_lmhead_(?:wide|f16)\w+):", text, flags=re.M)))
-    assert len(names) == 9, names        # k_lmhead_wide<1,2,4>, k_lmhead_f16<1,2,4,8,16>, k_lmhead_f16_fused
+    assert len(names) == 10, names       # k_lmhead_wide<1,2,4>, k_lmhead_f16<1,2,4,8,16>, k_lmhead_f16_fused<false / true>
     tiled = sorted(set(re.findall(r"^(_ZN3pio\d+k_dec_gemm_b\w+):", text, flags=re.M)))
     assert len(tiled) >= 12, tiled       # k_dec_gemm_b: qkv / fc (3 shapes each), proj (2 x 2 epilogues), fc2 (3)
     names += tiled

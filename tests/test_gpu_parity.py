@@ -434,6 +434,60 @@ def test_lm_head_fp16_filter_equals_the_exact_head_on_adversarial_vocabularies()
         e.close()
 
 
+def test_lm_head_ticketed_tail_gives_the_same_ids(golden, monkeypatch):
+    """PIO_LM_TAIL=1 when the engine is created: at <= 16 prefixes the arg-max filter runs as the ticketed tail of the LM head kernel
+    (the last N workgroups to arrive take a row each; decoder.hip: k_lmhead_f16_fused<true>) instead of as a launch of its own.  Off by
+    default (measured slower); held here to the golden ids, to the exact head on the adversarial vocabulary of the test above, over
+    repeated decodes (the tickets re-arm) and beside a clone decoding concurrently (a clone has its own tickets)."""
+    from patchioner_amd.engine import Engine
+    monkeypatch.setenv("PIO_LM_TAIL", "1")
+    g = golden("decoder")
+    e = Engine(embed_dim=768, depth=1, num_heads=12, num_registers=4, crop_dim=224, max_batch=2, max_prefixes=64, vit_dtype="fp16")
+    try:
+        e.load_state_dict(W.synth_decap(gc.DEC["seed_w"]))
+        e.finalize()
+        x = gc.decoder_prefixes("unit")
+        want = g["unit_ids"]
+        for N in (x.shape[0], 5, 1, 16):
+            big = x.repeat(-(-N // x.shape[0]), 1)[:N]
+            for _ in range(3):
+                ids, _ = e.decode_greedy(big)
+                assert np.array_equal(ids.cpu().numpy(), np.tile(want, (-(-N // x.shape[0]), 1))[:N]), N
+        c = e.clone_decoder()
+        try:
+            s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+            xd = x.cuda()
+            torch.cuda.synchronize()
+            for _ in range(4):
+                with torch.cuda.stream(s1):
+                    a, _ = e.decode_greedy(xd)
+                with torch.cuda.stream(s2):
+                    b, _ = c.decode_greedy(xd)
+            torch.cuda.synchronize()
+            assert np.array_equal(a.cpu().numpy(), want) and np.array_equal(b.cpu().numpy(), want)
+        finally:
+            c.close()
+    finally:
+        e.close()
+    sd = W.synth_decap(21)
+    wte = sd["decoder.transformer.wte.weight"]
+    gen = torch.Generator().manual_seed(5)
+    d = torch.tensor([0.0, 1e-4, -1e-4])[torch.randint(0, 3, (24704,), generator=gen)]
+    wte[1:49408:2] = wte[0:49408:2] * (1.0 + d[:, None])
+    e = Engine(embed_dim=768, depth=1, num_heads=12, num_registers=4, crop_dim=224, max_batch=2, vit_dtype="fp16")
+    try:
+        e.load_state_dict(sd)
+        e.finalize()
+        xr = torch.randn(16, 768, generator=gen)
+        for scale in (1.0, 1e3, 1e-3):
+            for N in (16, 5):
+                ids_f, _ = e.decode_greedy((xr[:N] * scale).contiguous())
+                ids_e, _ = e.decode_greedy((xr[:N] * scale).contiguous(), want_logprob=True)
+                assert torch.equal(ids_f.cpu(), ids_e.cpu()), (scale, N)
+    finally:
+        e.close()
+
+
 # ------------------------------------------------------------------------------------------- a14/a15
 def _make_model(with_bank, **over):
     from patchioner_amd import Patchioner
